@@ -1,0 +1,120 @@
+"""ctypes binding of oracle/_build/libl3oracle.so (TEST INFRASTRUCTURE: the CPU parity oracle).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "libl3oracle.so")
+DATA = os.path.join(ROOT, "tokenizer_amd", "data")
+
+
+def build_oracle():
+    """Compile the C restatement if it is missing or stale (gcc only; a few seconds)."""
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("l3_oracle.c", "l3_oracle.h", "unicode15_ranges.h")]
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+        return LIB
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return LIB
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        L.l3o_new.restype = C.c_void_p
+        L.l3o_new.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.l3o_free.argtypes = [C.c_void_p]
+        L.l3o_set_cache.argtypes = [C.c_void_p, C.c_int]
+        L.l3o_encode.restype = C.c_int64
+        L.l3o_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.l3o_pretokenize.restype = C.c_int64
+        L.l3o_pretokenize.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.l3o_pretokenize_strings.restype = C.c_int64
+        L.l3o_pretokenize_strings.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.l3o_split_document.restype = C.c_int64
+        L.l3o_split_document.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.l3o_decode.restype = C.c_int64
+        L.l3o_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.l3o_rune_class.restype = C.c_int
+        L.l3o_rune_class.argtypes = [C.c_uint32]
+        L.l3o_vocab_size.restype = C.c_int
+        L.l3o_vocab_size.argtypes = [C.c_void_p]
+        L.l3o_bpe_raw.restype = C.c_int64
+        L.l3o_bpe_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.l3o_encode_batch.restype = C.c_int64
+        L.l3o_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        vocab = open(os.path.join(DATA, "vocab_base64.txt"), "rb").read()
+        merges = open(os.path.join(DATA, "merges_binary.txt"), "rb").read()
+        self.h = L.l3o_new(vocab, len(vocab), merges, len(merges))
+        assert self.h, "oracle failed to load the vocabulary data"
+
+    def encode(self, text: bytes, bos=True, eos=True):
+        cap = len(text) * 3 + 8
+        out = np.empty(cap, dtype=np.int32)
+        n = self.lib.l3o_encode(self.h, text, len(text), int(bos), int(eos), out.ctypes.data, cap)
+        assert n <= cap
+        return out[:n].tolist()
+
+    def pretokenize(self, text: bytes):
+        cap = len(text) + 1
+        st = np.empty(cap, dtype=np.uint32)
+        n = self.lib.l3o_pretokenize(text, len(text), st.ctypes.data, cap)
+        return st[:n].tolist()
+
+    def pretokenize_strings(self, text: bytes):
+        cap = len(text) + 1
+        buf = np.empty(len(text) * 3 + 8, dtype=np.uint8)
+        ends = np.empty(cap, dtype=np.uint32)
+        n = self.lib.l3o_pretokenize_strings(text, len(text), buf.ctypes.data, buf.size, ends.ctypes.data, cap)
+        assert n >= 0
+        out, s = [], 0
+        raw = buf.tobytes()
+        for e in ends[:n].tolist():
+            out.append(raw[s:e]); s = e
+        return out
+
+    def split_document(self, text: bytes):
+        cap = len(text) + 1
+        st = np.empty(cap, dtype=np.uint32)
+        kd = np.empty(cap, dtype=np.uint8)
+        n = self.lib.l3o_split_document(text, len(text), st.ctypes.data, kd.ctypes.data, cap)
+        return st[:n].tolist(), kd[:n].tolist()
+
+    def decode(self, ids):
+        a = np.asarray(ids, dtype=np.int64).clip(-2**31, 2**31 - 1).astype(np.int32)
+        cap = a.size * 128 + 8
+        out = np.empty(cap, dtype=np.uint8)
+        n = self.lib.l3o_decode(self.h, a.ctypes.data, a.size, out.ctypes.data, cap)
+        return out[:n].tobytes()
+
+    def rune_class(self, cp):
+        return self.lib.l3o_rune_class(cp)
+
+    def bpe_raw(self, raw: bytes):
+        cap = len(raw) + 8
+        out = np.empty(cap, dtype=np.int32)
+        n = self.lib.l3o_bpe_raw(self.h, raw, len(raw), out.ctypes.data, cap)
+        return out[:n].tolist()
+
+    def encode_batch(self, text: np.ndarray, doc_off: np.ndarray, bos=True, eos=True, threads=1):
+        """text: uint8 array, doc_off: uint64 array (n+1). Returns (tokens int32, offsets uint64)."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        n_docs = doc_off.size - 1
+        cap = int(text.size) * 3 + 2 * n_docs + 8
+        out = np.empty(cap, dtype=np.int32)
+        off = np.empty(n_docs + 1, dtype=np.uint64)
+        n = self.lib.l3o_encode_batch(self.h, text.ctypes.data, doc_off.ctypes.data, n_docs, int(bos), int(eos),
+                                      out.ctypes.data, cap, off.ctypes.data, threads)
+        assert n >= 0
+        return out[:n].copy(), off
+
+    def set_cache(self, on):
+        self.lib.l3o_set_cache(self.h, int(on))
