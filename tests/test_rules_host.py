@@ -1,0 +1,127 @@
+"""CPU tests of the host/device-shared logic (position-local pre-tokenizer rules, table probes,
+merge loop) and of the table builder, against the oracle.  No GPU needed."""
+import base64
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from tests import corpus
+from tests.hostshim import HostShim
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def shim():
+    return HostShim()
+
+
+def test_table_stats(shim):
+    s = shim.stats()
+    assert s["n_tokens"] == 128256 and s["n_merges"] == 280147
+    assert s["class_blocks"] < 1024
+
+
+def test_classes_match_oracle_everywhere(shim, oracle):
+    # class codes: 1 letter, 2 digit; white space is 3 (NL), 4 (SP) or 5 (other)
+    for cp in list(range(0, 0x3400)) + list(range(0x4DB0, 0x4E10)) + list(range(0x9FF0, 0xD800)) + \
+            list(range(0xE000, 0x14700)) + list(range(0x16000, 0x19000)) + list(range(0x1AFF0, 0x20010)) + \
+            list(range(0x2A6D0, 0x2A710)) + list(range(0x2B730, 0x2B830)) + list(range(0x2CEA0, 0x2CEC0)) + \
+            list(range(0x2EBE0, 0x2EE70)) + list(range(0x2F800, 0x2FA20)) + list(range(0x30000, 0x32400)) + \
+            [0xE0001, 0x10FFFF]:
+        o = oracle.rune_class(cp)
+        c = shim.class_of(cp)
+        exp = 1 if o & 1 else 2 if o & 2 else (3 if cp in (10, 13) else 4 if cp == 32 else 5) if o & 4 else 0
+        assert c == exp, hex(cp)
+
+
+def test_vocab_lookup_and_decode_table(shim, oracle):
+    rng = random.Random(1)
+    ids = list(range(0, 300)) + [rng.randrange(128000) for _ in range(3000)] + list(range(127990, 128000))
+    for tid in ids:
+        raw = shim.token_bytes(tid)
+        assert raw == oracle.decode([tid])
+        assert shim.vocab_lookup(raw) == tid
+    assert shim.vocab_lookup(b"definitely not a token \x00") == -1
+    assert shim.token_bytes(128000) == b"<|begin_of_text|>" and shim.token_bytes(128255) == b"<|reserved_special_token_247|>"
+    assert shim.token_bytes(128256) is None
+
+
+def test_every_vocab_entry_found(shim):
+    for tid in range(128000):
+        assert shim.vocab_lookup(shim.token_bytes(tid)) == tid
+
+
+def test_pair_priorities_follow_rank_order(shim):
+    md = base64.b64decode(open(os.path.join(os.path.dirname(G), "..", "tokenizer_amd", "data", "merges_binary.txt"), "rb").read())
+    bits = np.unpackbits(np.frombuffer(md, dtype=np.uint8))
+    n = bits.size // 17
+    ids = bits[:n * 17].reshape(-1, 17).dot(1 << np.arange(16, -1, -1)).astype(np.int64)
+    pairs = ids[:n // 2 * 2].reshape(-1, 2)
+    assert pairs.shape[0] == 280147
+    rng = random.Random(2)
+    idx = sorted(set([0, 1, 2, 280146] + [rng.randrange(280147) for _ in range(20000)]))
+    prios = [shim.pair_prio(int(pairs[i, 0]), int(pairs[i, 1])) for i in idx]
+    assert all(p >= 0 for p in prios)
+    assert all(a < b for a, b in zip(prios, prios[1:]))          # order-isomorphic to rank
+    assert shim.pair_prio(5, 5) == -1 or (5, 5) in set(map(tuple, pairs.tolist()))
+
+
+def _check_split(shim, oracle, text):
+    assert shim.split_document(text) == oracle.split_document(text), text
+
+
+def test_split_on_reference_kat_inputs(shim, oracle):
+    for c in json.load(open(os.path.join(G, "ref_pretokenize_kats.json")))["cases"]:
+        _check_split(shim, oracle, bytes.fromhex(c["input"]))
+    enc = json.load(open(os.path.join(G, "ref_encode_kats.json")))
+    for c in enc["encode"]:
+        _check_split(shim, oracle, bytes.fromhex(c["input"]))
+    _check_split(shim, oracle, bytes.fromhex(enc["large"]["input"]))
+
+
+def test_split_exhaustive_short(shim, oracle):
+    # exhaustive over a small alphabet that exercises every rule, lengths 0..5
+    alpha = [b"a", b"s", b"'", b" ", b"\t", b"\n", b"1", b"!", "é".encode(), " ".encode(), b"\xff"]
+    import itertools
+    for n in range(0, 6):
+        for combo in itertools.product(alpha, repeat=n):
+            _check_split(shim, oracle, b"".join(combo))
+
+
+def test_split_fuzz(shim, oracle):
+    rng = random.Random(1234)
+    for _ in range(30000):
+        _check_split(shim, oracle, corpus.random_doc(rng))
+    for _ in range(3000):
+        _check_split(shim, oracle, corpus.random_bytes_doc(rng, rng.randint(0, 40)))
+    for s in corpus.SPECIALS + corpus.NEAR_MISSES:
+        _check_split(shim, oracle, s)
+        _check_split(shim, oracle, b"x " + s + b"\n y")
+        _check_split(shim, oracle, s[:-1])
+
+
+def test_split_long_runs(shim, oracle):
+    for t in (b"1" * 1000, b"a" * 1000, b" " * 1000, b"word " * 200, b"'s" * 100, b"\n \n " * 50, "٣".encode() * 100,
+              b"12" + "٣".encode() * 5 + b"7" * 8, b"\t" * 70 + b"x"):
+        _check_split(shim, oracle, t)
+
+
+def test_bpe_matches_oracle(shim, oracle):
+    rng = random.Random(7)
+    words = [corpus.random_word(rng) for _ in range(20000)]
+    words += [w.encode() for w in ["grabbed", " grabbed", "tokenization", " antidisestablishmentarianism", "镇", "🦙", "🦙Ꙋ",
+                                   " việc", "ektedir", " Привет", "文字文字文字", "�", "a�b"]]
+    words += [corpus.random_bytes_doc(rng, rng.randint(1, 20)).replace(b"\xff", b"a") for _ in range(2000)]
+    for w in words:
+        assert shim.bpe(w) == oracle.bpe_raw(w), w
+
+
+def test_bpe_unreachable_tokens(shim, oracle):
+    # the 588 vocabulary entries the merge rules cannot build are found by the whole-string lookup
+    for tid in (100769, 100827, 101503, 101673, 103084):
+        raw = shim.token_bytes(tid)
+        assert shim.bpe(raw) == [tid] == oracle.bpe_raw(raw)

@@ -1,0 +1,82 @@
+// l3_common.h -- constants, device-table layout and hash functions shared by the host table
+// builder (l3_tables.cpp) and the HIP kernels (l3_kernels.hip).  Host- and device-compilable.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define L3_HD __host__ __device__ __forceinline__
+#else
+#define L3_HD inline
+#endif
+
+namespace l3 {
+
+// ---- vocabulary facts (reference: llama3/constants.go:6-10, internal/tokens/special.go:19-40)
+constexpr int kBaseVocab = 128000;
+constexpr int kNumSpecial = 256;
+constexpr int kBosId = 128000;  // <|begin_of_text|>
+constexpr int kEosId = 128001;  // <|end_of_text|>
+constexpr int kMaxSpecialLen = 30;  // "<|reserved_special_token_247|>"
+constexpr int kMaxTokenBytes = 128; // longest vocabulary entry (raw bytes)
+
+// ---- merge priority ---------------------------------------------------------------------------
+// The reference orders candidate merges by rank = 1-based index of the pair in the merge file
+// (internal/vocabulary/decoder.go:67, bpe.go:126).  In that file all pairs producing the same
+// token are consecutive and product ids never decrease, so
+//     prio = (merged_id << 7) | index_of_pair_within_its_product      (24 bits)
+// is order-isomorphic to rank AND carries the merged id; the table builder verifies both facts
+// and refuses data for which they do not hold.
+constexpr uint32_t kNoPrio = 0xFFFFFFFFu;
+L3_HD uint32_t prio_merged_id(uint32_t prio) { return prio >> 7; }
+
+// ---- pair table: (idA,idB) -> prio, open addressing, 8-byte slots -----------------------------
+// slot = key34 << 24 | prio24 ; empty = ~0.  key34 = idA << 17 | idB.
+constexpr uint64_t kPairEmpty = ~0ull;
+L3_HD uint64_t pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << 17) | (uint64_t)b; }
+L3_HD uint32_t pair_hash(uint64_t key, uint32_t log2_slots) {
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2_slots));
+}
+
+// ---- vocabulary table: raw token bytes -> id, open addressing, 16-byte slots ------------------
+// w[3] = id | len << 17 ; len <= 12: w[0..2] hold the bytes (little endian, zero padded);
+// len > 12: w[0] = second hash, w[1] = offset of the bytes in the blob, w[2] = 0.
+// empty slot: w[3] = 0xFFFFFFFF.
+struct VocabSlot { uint32_t w[4]; };
+constexpr uint32_t kVocabEmpty = 0xFFFFFFFFu;
+constexpr int kVocabInline = 12;
+// two running FNV-1a style hashes over the (expanded) pre-token bytes
+struct StrHash { uint32_t h1, h2; };
+L3_HD StrHash strhash_init() { return StrHash{2166136261u, 0x9747B28Cu}; }
+L3_HD void strhash_add(StrHash& h, uint32_t byte) {
+    h.h1 = (h.h1 ^ byte) * 16777619u;
+    h.h2 = (h.h2 + byte + 1u) * 0x85EBCA6Bu; h.h2 ^= h.h2 >> 15;
+}
+L3_HD uint32_t strhash_slot(const StrHash& h, uint32_t len, uint32_t log2_slots) {
+    uint32_t x = h.h1 ^ (len * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x >> (32 - log2_slots);
+}
+
+// ---- character classes ------------------------------------------------------------------------
+// two-stage table: stage1[cp >> 8] -> block; block = 64 bytes, 2 bits per code point:
+// 0 other, 1 letter (L*), 2 decimal digit (Nd), 3 white space (unicode.IsSpace)
+constexpr int kClsStage1 = 0x110000 >> 8;  // 4352
+
+// device-resident tables (all pointers are device pointers when used by kernels)
+struct Tables {
+    const uint16_t* cls_stage1;   // [kClsStage1]
+    const uint8_t* cls_blocks;    // [n_blocks][64]
+    const uint8_t* byte_tok;      // [256] token id of each single byte (ids 0..255)
+    const uint32_t* bytepair;     // [65536] prio of (byte a, byte b) indexed a<<8|b, kNoPrio if no rule
+    const uint64_t* pair_slots;   // [1 << pair_log2]
+    const VocabSlot* vocab_slots; // [1 << vocab_log2]
+    const uint8_t* vocab_blob;    // raw bytes of tokens longer than kVocabInline
+    const int32_t* special_id;    // [256] canonical special index -> token id (0 = not a token)
+    uint32_t pair_log2;
+    uint32_t vocab_log2;
+};
+
+// canonical special index: 0..7 = the named tokens in regex order (special.go:12), 8+k = reserved_k
+constexpr int kSpecialNamed = 8;
+
+}  // namespace l3

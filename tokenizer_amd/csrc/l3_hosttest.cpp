@@ -1,0 +1,142 @@
+// l3_hosttest.cpp -- host build of the host/device-shared headers (l3_rules.h, l3_bpe.h) and of the
+// table builder, exported for the CPU test-suite (tests/test_rules_host.py).  It lets the position-local
+// pre-tokenizer rules, the table probes and the merge loop be fuzzed against the oracle without a
+// GPU.  It is a unit-test shim: nothing in the product calls it and it is not a CPU fallback.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "l3_bpe.h"
+#include "l3_rules.h"
+#include "l3_tables.h"
+
+using namespace l3;
+
+namespace {
+struct Handle {
+    HostTables H;
+    Tables T;
+};
+struct DocBytes {  // byte source over one whole document
+    const uint8_t* t; int64_t n;
+    uint32_t b(int64_t q) const { return t[q]; }
+    bool ds(int64_t q) const { return q == 0 || q == n; }
+    int64_t lo() const { return 0; }
+    int64_t hi() const { return n; }
+};
+struct DocInfo {
+    const uint16_t* w; int64_t n;
+    uint32_t info(int64_t q) const { return w[q]; }
+    int64_t lo() const { return 0; }
+    int64_t hi() const { return n; }
+};
+}  // namespace
+
+extern "C" {
+
+void* l3t_create(const void* vocab, size_t vlen, const void* merges, size_t mlen) {
+    Handle* h = new Handle();
+    if (!build_tables(vocab, vlen, merges, mlen, h->H)) { delete h; return nullptr; }
+    h->T.cls_stage1 = h->H.cls_stage1.data();
+    h->T.cls_blocks = h->H.cls_blocks.data();
+    h->T.byte_tok = h->H.byte_tok;
+    h->T.bytepair = h->H.bytepair.data();
+    h->T.pair_slots = h->H.pair_slots.data();
+    h->T.vocab_slots = h->H.vocab_slots.data();
+    h->T.vocab_blob = h->H.vocab_blob.data();
+    h->T.special_id = h->H.special_id;
+    h->T.pair_log2 = h->H.pair_log2;
+    h->T.vocab_log2 = h->H.vocab_log2;
+    return h;
+}
+void l3t_destroy(void* p) { delete (Handle*)p; }
+
+// table statistics: [n_tokens, n_merges, pair_log2, vocab_log2, class blocks, vocab blob bytes]
+void l3t_stats(void* p, int64_t* out) {
+    Handle* h = (Handle*)p;
+    out[0] = h->H.n_tokens; out[1] = h->H.n_merges; out[2] = h->H.pair_log2; out[3] = h->H.vocab_log2;
+    out[4] = (int64_t)h->H.cls_blocks.size() / 64; out[5] = (int64_t)h->H.vocab_blob.size();
+}
+
+int l3t_class_of(void* p, uint32_t cp) {
+    Handle* h = (Handle*)p;
+    return (int)class_of_cp(cp, h->T.cls_stage1, h->T.cls_blocks);
+}
+
+// per-byte info words of one document (special-token overlay applied), as the tile kernel builds them
+static void doc_info(Handle* h, const uint8_t* text, int64_t n, std::vector<uint16_t>& w, std::vector<int32_t>& spid) {
+    DocBytes a{text, n};
+    w.assign((size_t)n + 1, 0);
+    spid.assign((size_t)n + 1, 0);
+    for (int64_t p = 0; p < n; p++) w[p] = (uint16_t)byte_info(a, p, h->T.cls_stage1, h->T.cls_blocks);
+    w[n] = I_SEG | I_RUNE;
+    for (int64_t p = 0; p < n; p++) {
+        if (text[p] != '<') continue;
+        int canon = 0;
+        int len = special_match(a, p, &canon);
+        if (!len) continue;
+        int32_t id = h->T.special_id[canon];
+        w[p] |= I_SEG;
+        w[p + len] |= I_SEG;
+        if (id != 0) {
+            w[p] |= I_SPECIAL;
+            spid[p] = id;
+            for (int k = 1; k < len; k++) w[p + k] = I_SPBODY;
+        }
+    }
+}
+
+int64_t l3t_split_document(void* hp, const uint8_t* text, int64_t n, uint32_t* starts, uint8_t* kinds, int64_t cap) {
+    Handle* h = (Handle*)hp;
+    std::vector<uint16_t> w; std::vector<int32_t> spid;
+    doc_info(h, text, n, w, spid);
+    DocInfo s{w.data(), n};
+    int64_t cnt = 0;
+    for (int64_t p = 0; p < n; p++) {
+        uint32_t x = w[p];
+        if (!(x & I_RUNE) || (x & I_SPBODY)) continue;
+        int doff = 0;
+        if ((x & I_CLS) == C_N && !(x & (I_SEG | I_SPECIAL))) doff = digits_before(s, p);
+        if (!starts_pretoken(s, p, doff)) continue;
+        if (cnt < cap) { starts[cnt] = (uint32_t)p; kinds[cnt] = (x & I_SPECIAL) ? 1 : 0; }
+        cnt++;
+    }
+    return cnt;
+}
+
+int64_t l3t_pair_prio(void* hp, uint32_t a, uint32_t b) {
+    uint32_t v = pair_prio(((Handle*)hp)->T, a, b);
+    return v == kNoPrio ? -1 : (int64_t)v;
+}
+
+int32_t l3t_vocab_lookup(void* hp, const uint8_t* bytes, uint32_t n) {
+    return vocab_lookup(((Handle*)hp)->T, [&](uint32_t i) { return (uint32_t)bytes[i]; }, n);
+}
+
+// PerformBPE on the raw (already U+FFFD-expanded) bytes of one pre-token, the way the kernels do it.
+int64_t l3t_bpe(void* hp, const uint8_t* bytes, int64_t n, int32_t* out, int64_t cap) {
+    Handle* h = (Handle*)hp;
+    int32_t id = vocab_lookup(h->T, [&](uint32_t i) { return (uint32_t)bytes[i]; }, (uint32_t)n);
+    if (id >= 0) { if (cap > 0) out[0] = id; return 1; }
+    std::vector<int32_t> sym((size_t)n);
+    std::vector<uint32_t> pr((size_t)n, kNoPrio);
+    for (int64_t i = 0; i < n; i++) sym[i] = h->T.byte_tok[bytes[i]];
+    for (int64_t i = 0; i + 1 < n; i++) pr[i] = h->T.bytepair[((uint32_t)bytes[i] << 8) | bytes[i + 1]];
+    merge_span(h->T, sym, pr, 0, (int)n);
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (sym[i] >= 0) { if (k < cap) out[k] = sym[i]; k++; }
+    return k;
+}
+
+// Decode table access for tests: raw bytes of token id (tokenizer.go:339-354)
+int64_t l3t_token_bytes(void* hp, int32_t id, uint8_t* out, int64_t cap) {
+    Handle* h = (Handle*)hp;
+    if (id < 0 || id >= h->H.n_tokens) return -1;
+    int64_t l = h->H.tok_off[id + 1] - h->H.tok_off[id];
+    memcpy(out, h->H.tok_bytes.data() + h->H.tok_off[id], (size_t)(l < cap ? l : cap));
+    return l;
+}
+
+}  // extern "C"

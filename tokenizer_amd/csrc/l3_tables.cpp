@@ -1,0 +1,246 @@
+// l3_tables.cpp -- see l3_tables.h.  Host only (plain C++17).
+#include "l3_tables.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <unordered_map>
+
+#include "unicode15_ranges.h"
+
+namespace l3 {
+
+namespace {
+
+bool b64_decode(const uint8_t* s, size_t n, std::vector<uint8_t>& out) {
+    int8_t lut[256];
+    memset(lut, -1, sizeof lut);
+    const char* alpha = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    for (int i = 0; i < 64; i++) lut[(uint8_t)alpha[i]] = (int8_t)i;
+    out.clear();
+    out.reserve(n / 4 * 3 + 3);
+    uint32_t acc = 0;
+    int bits = 0;
+    bool pad = false;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t c = s[i];
+        if (c == '\n' || c == '\r') continue;  // Go's decoder skips line breaks
+        if (c == '=') { pad = true; continue; }
+        if (pad || lut[c] < 0) return false;
+        acc = (acc << 6) | (uint32_t)lut[c];
+        bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+    }
+    return true;
+}
+
+// Inverse of the GPT-2 byte <-> printable-rune map (reference encoding.go:35-80): code point -> byte.
+void build_unicode_to_byte(int16_t u2b[512], uint16_t b2u[256]) {
+    for (int i = 0; i < 512; i++) u2b[i] = -1;
+    int next = 256;
+    for (int b = 0; b < 256; b++) {
+        bool printable = (b >= 0x21 && b <= 0x7E) || (b >= 0xA1 && b <= 0xAC) || (b >= 0xAE);
+        int cp = printable ? b : next++;
+        b2u[b] = (uint16_t)cp;
+        u2b[cp] = (int16_t)b;
+    }
+}
+
+struct BitReader {  // big-endian bit stream (merges file: 17-bit ids, decoder.go:75-126)
+    const uint8_t* p; size_t nbits; size_t pos = 0;
+    bool has(int k) const { return pos + (size_t)k <= nbits; }
+    uint32_t get(int k) {
+        uint32_t v = 0;
+        for (int i = 0; i < k; i++, pos++) v = (v << 1) | ((p[pos >> 3] >> (7 - (pos & 7))) & 1u);
+        return v;
+    }
+};
+
+int cls_of(uint32_t cp) {
+    auto in = [&](const unsigned (*t)[2], unsigned n) {
+        unsigned lo = 0, hi = n;
+        while (lo < hi) {
+            unsigned mid = (lo + hi) / 2;
+            if (cp < t[mid][0]) hi = mid; else if (cp > t[mid][1]) lo = mid + 1; else return true;
+        }
+        return false;
+    };
+    if (in(L3_UNI_LETTER, L3_UNI_LETTER_COUNT)) return 1;
+    if (in(L3_UNI_DIGIT, L3_UNI_DIGIT_COUNT)) return 2;
+    if (in(L3_UNI_SPACE, L3_UNI_SPACE_COUNT)) return 3;
+    return 0;
+}
+
+void build_class_tables(HostTables& T) {
+    T.cls_stage1.assign(kClsStage1, 0);
+    T.cls_blocks.clear();
+    std::unordered_map<std::string, uint16_t> seen;
+    for (int blk = 0; blk < kClsStage1; blk++) {
+        std::string b(64, '\0');
+        for (int i = 0; i < 256; i++) {
+            int c = cls_of((uint32_t)blk * 256 + (uint32_t)i);
+            b[i >> 2] = (char)((uint8_t)b[i >> 2] | (c << ((i & 3) * 2)));
+        }
+        auto it = seen.find(b);
+        if (it == seen.end()) {
+            uint16_t idx = (uint16_t)(T.cls_blocks.size() / 64);
+            T.cls_blocks.insert(T.cls_blocks.end(), b.begin(), b.end());
+            it = seen.emplace(b, idx).first;
+        }
+        T.cls_stage1[blk] = it->second;
+    }
+}
+
+}  // namespace
+
+std::string special_name(int i) {
+    static const char* named[kSpecialNamed] = {"begin_of_text", "end_of_text", "start_header_id", "end_header_id",
+                                               "eot_id", "eom_id", "python_tag", "finetune_right_pad_id"};
+    if (i < kSpecialNamed) return std::string("<|") + named[i] + "|>";
+    return "<|reserved_special_token_" + std::to_string(i - kSpecialNamed) + "|>";
+}
+
+// ids follow the order of GetDefaultSpecialTokens (special.go:19-40): the list index + 128000
+int special_default_id(int i) {
+    static const int named_id[kSpecialNamed] = {128000, 128001, 128006, 128007, 128009, 128008, 128010, 128004};
+    if (i < kSpecialNamed) return named_id[i];
+    int k = i - kSpecialNamed;  // reserved_special_token_k
+    if (k == 0) return 128002;
+    if (k == 1) return 128003;
+    if (k == 2) return 128005;
+    return 128008 + k;
+}
+
+bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len, HostTables& T) {
+    std::vector<uint8_t> vtxt, mbin;
+    if (!vocab_b64 || !b64_decode((const uint8_t*)vocab_b64, vocab_len, vtxt) || vtxt.empty()) {
+        T.error = "decode vocabulary base64"; return false;
+    }
+    if (!merges_b64 || !b64_decode((const uint8_t*)merges_b64, merges_len, mbin)) {
+        T.error = "decode merges base64"; return false;
+    }
+    int16_t u2b[512]; uint16_t b2u[256];
+    build_unicode_to_byte(u2b, b2u);
+
+    // ---- vocabulary: one token per non-empty line, id = line index; text is in the byte-level alphabet
+    T.tok_bytes.clear(); T.tok_off.clear();
+    std::unordered_map<std::string, int> by_bytes;
+    by_bytes.reserve(1 << 18);
+    size_t i = 0;
+    while (i <= vtxt.size()) {
+        size_t e = i;
+        while (e < vtxt.size() && vtxt[e] != '\n') e++;
+        if (e > i) {
+            T.tok_off.push_back((uint32_t)T.tok_bytes.size());
+            size_t start = T.tok_bytes.size();
+            for (size_t k = i; k < e;) {  // UTF-8 decode of code points < 0x200
+                uint32_t cp; uint8_t c = vtxt[k];
+                if (c < 0x80) { cp = c; k += 1; }
+                else if ((c & 0xE0) == 0xC0 && k + 1 < e) { cp = ((uint32_t)(c & 0x1F) << 6) | (vtxt[k + 1] & 0x3F); k += 2; }
+                else { T.error = "vocabulary entry outside the byte-level alphabet"; return false; }
+                if (cp >= 512 || u2b[cp] < 0) { T.error = "vocabulary entry outside the byte-level alphabet"; return false; }
+                T.tok_bytes.push_back((uint8_t)u2b[cp]);
+            }
+            std::string key((const char*)T.tok_bytes.data() + start, T.tok_bytes.size() - start);
+            by_bytes[key] = (int)T.tok_off.size() - 1;  // later duplicates win, as in tokenizer.go:201-204
+        }
+        i = e + 1;
+    }
+    int n_base = (int)T.tok_off.size();
+    if (n_base < 256 || n_base > (1 << 17) - kNumSpecial) { T.error = "unsupported vocabulary size"; return false; }
+    // special tokens are appended after the base vocabulary (tokenizer.go:194-198)
+    for (int k = 0; k < kNumSpecial; k++) T.special_id[k] = 0;
+    {
+        // list order of GetDefaultSpecialTokens: invert special_default_id
+        std::vector<std::string> by_list(kNumSpecial);
+        for (int c = 0; c < kNumSpecial; c++) by_list[special_default_id(c) - 128000] = special_name(c);
+        for (int k = 0; k < kNumSpecial; k++) {
+            T.tok_off.push_back((uint32_t)T.tok_bytes.size());
+            T.tok_bytes.insert(T.tok_bytes.end(), by_list[k].begin(), by_list[k].end());
+        }
+        for (int c = 0; c < kNumSpecial; c++) T.special_id[c] = n_base + (special_default_id(c) - 128000);
+    }
+    T.tok_off.push_back((uint32_t)T.tok_bytes.size());
+    T.n_tokens = n_base + kNumSpecial;
+    auto tok = [&](int id) { return std::string((const char*)T.tok_bytes.data() + T.tok_off[id], T.tok_off[id + 1] - T.tok_off[id]); };
+
+    // ---- single-byte tokens
+    for (int b = 0; b < 256; b++) {
+        auto it = by_bytes.find(std::string(1, (char)b));
+        if (it == by_bytes.end() || it->second > 255) { T.error = "single-byte tokens must have ids 0..255"; return false; }
+        T.byte_tok[b] = (uint8_t)it->second;
+    }
+
+    // ---- merges: 17-bit id pairs, rank = pair index + 1
+    BitReader br{mbin.data(), mbin.size() * 8};
+    struct Rule { uint32_t a, b, merged, sub; };
+    std::vector<Rule> rules;
+    rules.reserve(mbin.size() * 8 / 34 + 1);
+    {
+        std::unordered_map<uint64_t, int> seen;
+        seen.reserve(1 << 19);
+        uint32_t last_merged = 0, sub = 0;
+        while (br.has(34)) {
+            uint32_t a = br.get(17), b = br.get(17);
+            if ((int)a >= n_base || (int)b >= n_base) { T.error = "merge rule references an unknown token id"; return false; }
+            auto it = by_bytes.find(tok((int)a) + tok((int)b));
+            if (it == by_bytes.end() || it->second >= n_base) { T.error = "merge rule whose product is not in the vocabulary"; return false; }
+            uint32_t m = (uint32_t)it->second;
+            if (!seen.emplace(pair_key(a, b), 1).second) { T.error = "duplicate merge rule"; return false; }
+            if (!rules.empty() && m < last_merged) { T.error = "merge rules are not grouped by ascending product id"; return false; }
+            sub = (!rules.empty() && m == last_merged) ? sub + 1 : 0;
+            if (sub >= 128) { T.error = "more than 128 merge rules for one product"; return false; }
+            last_merged = m;
+            rules.push_back(Rule{a, b, m, sub});
+        }
+    }
+    T.n_merges = (int)rules.size();
+
+    // pair hash table + direct byte-pair table
+    T.pair_log2 = 16;
+    while ((1ull << T.pair_log2) < rules.size() * 3) T.pair_log2++;  // load factor <= 1/3
+    T.pair_slots.assign(1ull << T.pair_log2, kPairEmpty);
+    T.bytepair.assign(65536, kNoPrio);
+    uint8_t tok_byte[256];  // id -> byte for ids 0..255
+    for (int b = 0; b < 256; b++) tok_byte[T.byte_tok[b]] = (uint8_t)b;
+    const uint64_t mask = (1ull << T.pair_log2) - 1;
+    for (const Rule& r : rules) {
+        uint32_t prio = (r.merged << 7) | r.sub;
+        uint64_t key = pair_key(r.a, r.b);
+        uint64_t s = pair_hash(key, T.pair_log2);
+        while (T.pair_slots[s] != kPairEmpty) s = (s + 1) & mask;
+        T.pair_slots[s] = (key << 24) | prio;
+        if (r.a < 256 && r.b < 256) T.bytepair[((uint32_t)tok_byte[r.a] << 8) | tok_byte[r.b]] = prio;
+    }
+
+    // ---- whole-string vocabulary table (bpe.go:27-33 looks the whole pre-token up first)
+    T.vocab_log2 = 16;
+    while ((1u << T.vocab_log2) < (uint32_t)n_base * 2u) T.vocab_log2++;
+    T.vocab_slots.assign(1u << T.vocab_log2, VocabSlot{{0, 0, 0, kVocabEmpty}});
+    T.vocab_blob.clear();
+    const uint32_t vmask = (1u << T.vocab_log2) - 1;
+    for (auto& kv : by_bytes) {
+        const std::string& s = kv.first;
+        uint32_t len = (uint32_t)s.size();
+        if (len == 0 || len > (uint32_t)kMaxTokenBytes) { T.error = "vocabulary entry longer than 128 bytes"; return false; }
+        StrHash h = strhash_init();
+        for (unsigned char c : s) strhash_add(h, c);
+        VocabSlot slot{{0, 0, 0, (uint32_t)kv.second | (len << 17)}};
+        if (len <= (uint32_t)kVocabInline) {
+            for (uint32_t k = 0; k < len; k++) slot.w[k >> 2] |= (uint32_t)(uint8_t)s[k] << ((k & 3) * 8);
+        } else {
+            slot.w[0] = h.h2;
+            slot.w[1] = (uint32_t)T.vocab_blob.size();
+            T.vocab_blob.insert(T.vocab_blob.end(), s.begin(), s.end());
+        }
+        uint32_t p = strhash_slot(h, len, T.vocab_log2);
+        while (T.vocab_slots[p].w[3] != kVocabEmpty) p = (p + 1) & vmask;
+        T.vocab_slots[p] = slot;
+    }
+    while (T.vocab_blob.size() % 16) T.vocab_blob.push_back(0);
+
+    build_class_tables(T);
+    return true;
+}
+
+}  // namespace l3

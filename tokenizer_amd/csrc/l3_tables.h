@@ -1,0 +1,42 @@
+// l3_tables.h -- host-side table builder: turns the reference's two data files into the tables the
+// HIP kernels read.  Stands where llama3.New() builds tokens/tokenLookup/mergeRules
+// (reference llama3/tokenizer.go:142-213, internal/vocabulary/decoder.go:16-126).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "l3_common.h"
+
+namespace l3 {
+
+struct HostTables {
+    std::vector<uint16_t> cls_stage1;
+    std::vector<uint8_t> cls_blocks;
+    uint8_t byte_tok[256];
+    std::vector<uint32_t> bytepair;
+    std::vector<uint64_t> pair_slots;
+    uint32_t pair_log2 = 0;
+    std::vector<VocabSlot> vocab_slots;
+    uint32_t vocab_log2 = 0;
+    std::vector<uint8_t> vocab_blob;
+    int32_t special_id[256];
+    // raw bytes of every token id (0..128255) for Decode (tokenizer.go:339-354)
+    std::vector<uint8_t> tok_bytes;
+    std::vector<uint32_t> tok_off;  // n_tokens + 1
+    int n_tokens = 0;
+    int n_merges = 0;
+    std::string error;
+};
+
+// Returns false and sets out.error on malformed or unsupported data.
+bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len,
+                  HostTables& out);
+
+// Name of the special token with canonical index i (0..255) and its default id.
+std::string special_name(int canonical_index);
+int special_default_id(int canonical_index);
+
+}  // namespace l3
