@@ -1,0 +1,90 @@
+/* l3hip.h -- C ABI of libl3hip.so: the Llama-3 encode path on AMD Instinct MI355X (gfx950).
+ *
+ * Drop-in boundary for the batch-encode hot path of agentstation/tokenizer.  Every entry point
+ * names the reference interface it stands for (paths relative to the reference repository).
+ * Plain C types only; the library never keeps a caller pointer after a call returns, so it can be
+ * bound from cgo without pinning (see INTEGRATION.md for the Go stubs).
+ *
+ * Threading: calls on one context are serialised internally; use one context per GPU and per
+ * concurrent stream of work.  There is no CPU fallback: if no gfx950 device is usable the calls fail.
+ */
+#ifndef L3HIP_H
+#define L3HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct l3_ctx l3_ctx;
+
+/* return codes */
+#define L3_OK 0
+#define L3_E_INVALID_ARG (-1) /* null pointer, offsets not ascending / not covering the text, ... */
+#define L3_E_DATA (-2)        /* vocabulary / merge data malformed  (reference: *DataError, errors.go) */
+#define L3_E_HIP (-3)         /* HIP runtime failure; l3_last_error() has the text */
+#define L3_E_OUTPUT_CAP (-4)  /* output buffer too small; *n_tok / *n_bytes holds the size needed */
+#define L3_E_NO_DEVICE (-5)   /* no usable gfx950 device */
+#define L3_E_NOT_FOUND (-6)   /* reference: ErrTokenNotFound / ErrInvalidToken (tokenizer.go:357-368) */
+
+/* EncodeOptions{BOS, EOS} (tokenizer.go:107-112); nil options == L3_BOS|L3_EOS (tokenizer.go:218-220) */
+#define L3_BOS 1u
+#define L3_EOS 2u
+
+/* llama3.New() (tokenizer.go:142-213): builds the tables from the contents of the reference's two
+ * embedded data files (internal/vocabulary/embed.go:13-20: vocab_base64.txt, merges_binary.txt) and
+ * uploads them to GPU `device`.  The 256 default special tokens (internal/tokens/special.go:19-40)
+ * are appended as the reference does.  On failure *out is NULL and l3_last_error(NULL) has the reason. */
+int l3_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len, int device,
+              l3_ctx** out);
+void l3_destroy(l3_ctx* ctx);
+/* text of the last error on this context (ctx == NULL: of the last failed l3_create on this thread) */
+const char* l3_last_error(const l3_ctx* ctx);
+
+/* Tokenizer.Encode / EncodeBytes / AppendTokens (tokenizer.go:217-330) for a BATCH of documents.
+ * Document i is text[doc_off[i] .. doc_off[i+1]); doc_off has n_docs+1 ascending entries, doc_off[0] = 0.
+ * Document i's ids are out_tok[out_off[i] .. out_off[i+1]); *n_tok = out_off[n_docs].
+ * Bytes may be arbitrary (invalid UTF-8 is handled as Go's []rune conversion does, state_machine.go:36).
+ * Host pointers.  If out_cap is too small nothing is written to out_tok and L3_E_OUTPUT_CAP is
+ * returned with *n_tok = the size needed (out_off is still filled in). */
+int l3_encode_batch(l3_ctx* ctx, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                    int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok);
+
+/* Same with DEVICE pointers (inputs already resident in HBM; outputs stay there).  `stream` is a
+ * hipStream_t (NULL: the context's own stream).  The call returns after the work has finished. */
+int l3_encode_batch_device(l3_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off,
+                           uint64_t n_docs, uint32_t flags, int32_t* d_out_tok, uint64_t out_cap,
+                           uint64_t* d_out_off, uint64_t* n_tok, void* stream);
+
+/* Tokenizer.PreTokenize (tokenizer.go:490-504) + tokens.SplitBySpecialTokens (special.go:48-83) as
+ * boundaries: kinds[i] = 1 if a pre-token starts at byte i, 2 if a special token starts there, else 0.
+ * Host pointers; kinds has doc_off[n_docs] entries. */
+int l3_pretokenize_batch(l3_ctx* ctx, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs,
+                         uint8_t* kinds);
+
+/* Tokenizer.DecodeBytes (tokenizer.go:339-354) for a batch of id sequences: ids outside
+ * [0, VocabSize) are skipped.  Host pointers; same capacity protocol as l3_encode_batch. */
+int l3_decode_batch(l3_ctx* ctx, const int32_t* ids, const uint64_t* id_off, uint64_t n_seqs, uint8_t* out_bytes,
+                    uint64_t out_cap, uint64_t* out_off, uint64_t* n_bytes);
+
+/* Tokenizer.GetSpecialTokenID (tokenizer.go:357-368): name like "<|eot_id|>". */
+int l3_special_token_id(const l3_ctx* ctx, const char* name, size_t name_len, int32_t* id);
+/* Tokenizer.VocabSize (tokenizer.go:420-422) */
+int l3_vocab_size(const l3_ctx* ctx);
+/* raw bytes of one token (what Decode appends for it); returns its length or L3_E_NOT_FOUND */
+int l3_token_bytes(const l3_ctx* ctx, int32_t id, uint8_t* out, size_t cap);
+
+/* Measurement support (no counterpart in the reference): when enabled, HIP events are recorded on the
+ * launch stream between the kernels of every encode call; l3_last_timings() returns the milliseconds of
+ * the last call: [0] validate+docs, [1] tile kernel, [2] slow kernel, [3] scan, [4] emit, [5] first
+ * kernel start -> last kernel end.  Returns the number of values written. */
+int l3_set_profiling(l3_ctx* ctx, int enabled);
+int l3_last_timings(l3_ctx* ctx, float* ms, int cap);
+/* counters of the last encode call: [0] tiles, [1] deferred (slow) pre-tokens, [2] tokens from them,
+ * [3] scratch bytes, [4] retries after a workspace grew */
+int l3_last_counters(l3_ctx* ctx, uint64_t* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

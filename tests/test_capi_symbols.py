@@ -1,0 +1,33 @@
+"""CPU checks of the drop-in boundary: the library loads and exports every symbol include/l3hip.h declares
+(no compute call is made without a GPU)."""
+import os
+import re
+
+from tokenizer_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_and_binding_agree():
+    hdr = open(os.path.join(ROOT, "include", "l3hip.h")).read()
+    declared = set(re.findall(r"\b(l3_[a-z_0-9]+)\s*\(", hdr))
+    bound = {name for name, _, _ in capi.SYMBOLS}
+    assert declared == bound, declared ^ bound
+
+
+def test_library_exports_every_symbol():
+    lib = capi.load_library()
+    for name, _, _ in capi.SYMBOLS:
+        assert getattr(lib, name) is not None
+
+
+def test_create_rejects_bad_data_without_gpu():
+    import ctypes as C
+    lib = capi.load_library()
+    h = C.c_void_p()
+    rc = lib.l3_create(b"!!!not base64!!!", 16, b"AAAA", 4, 0, C.byref(h))
+    assert rc == capi.L3_E_DATA and not h.value
+    assert b"vocabulary" in lib.l3_last_error(None)
+    vocab, merges = capi.read_data_files()
+    rc = lib.l3_create(vocab, len(vocab), merges[:1000], 1000, 0, C.byref(h))
+    assert rc in (capi.L3_E_DATA, capi.L3_E_NO_DEVICE) and not h.value

@@ -1,0 +1,277 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/l3hip.h) against the CPU oracle and the
+reference's own known-answer vectors.  Bit-exact: token ids, per-document offsets, boundaries.
+
+Run on the MI355X box:  python -u -m pytest tests -m gpu -x -v --timeout 120 --timeout-method thread
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from tests import corpus
+from tools import corpora
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+ENC = json.load(open(os.path.join(G, "ref_encode_kats.json")))
+PRE = json.load(open(os.path.join(G, "ref_pretokenize_kats.json")))["cases"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tokenizer_amd import capi
+    c = capi.Context(device=0)
+    yield c
+    c.close()
+
+
+def check_batch(ctx, oracle, docs, bos=True, eos=True, label=""):
+    """Encode `docs` as one batch on the GPU and compare with the oracle, document by document."""
+    from tokenizer_amd import capi
+    text, off = capi.pack_docs(docs)
+    got_tok, got_off = ctx.encode_batch(text, off, bos, eos)
+    exp_tok, exp_off = oracle.encode_batch(text, off, bos, eos, threads=8)
+    if np.array_equal(got_off, exp_off) and np.array_equal(got_tok, exp_tok):
+        return
+    go, eo = got_off.astype(np.int64), exp_off.astype(np.int64)
+    for i, d in enumerate(docs):
+        g = got_tok[go[i]:go[i + 1]].tolist() if go[i + 1] <= got_tok.size else None
+        e = exp_tok[eo[i]:eo[i + 1]].tolist()
+        if g != e:
+            k = next((j for j in range(min(len(g or []), len(e))) if g[j] != e[j]), min(len(g or []), len(e)))
+            raise AssertionError("%s: document %d of %d (len %d) differs at token %d\n  text[:200]=%r\n  got=%r\n  exp=%r" % (
+                label, i, len(docs), len(d), k, d[:200], (g or [])[max(0, k - 3):k + 8], e[max(0, k - 3):k + 8]))
+    raise AssertionError("%s: offsets differ although every document matches" % label)
+
+
+# ---- the reference's own known-answer vectors, through the GPU path ---------------------------------
+@pytest.mark.parametrize("case", ENC["encode"], ids=lambda c: "tokenizer_test.go:%s" % c["line"])
+def test_encode_kat(ctx, case):
+    got = ctx.encode_docs([bytes.fromhex(case["input"])], case["bos"], case["eos"])[0]
+    assert got == case["expected"]
+
+
+def test_encode_kats_as_one_batch(ctx):
+    for bos, eos in ((False, False), (True, True), (True, False), (False, True)):
+        cases = [c for c in ENC["encode"] if c["bos"] == bos and c["eos"] == eos]
+        got = ctx.encode_docs([bytes.fromhex(c["input"]) for c in cases], bos, eos)
+        assert got == [c["expected"] for c in cases]
+
+
+def test_large_text_kat(ctx):
+    text = bytes.fromhex(ENC["large"]["input"])
+    ids = ctx.encode_docs([text])[0]
+    assert len(ids) == 373  # tokenizer_test.go:322
+    out, off = ctx.decode_batch(np.array(ids, dtype=np.int32), np.array([0, len(ids)], dtype=np.uint64))
+    assert out.tobytes() == b"<|begin_of_text|>" + text + b"<|end_of_text|>"
+
+
+def test_readme_vectors(ctx):
+    # README.md:113-114, llama3/README.md:44
+    assert ctx.encode_docs([b"Hello, world!"])[0] == [128000, 9906, 11, 1917, 0, 128001]
+    assert ctx.encode_docs([b"Hello world!"])[0] == [128000, 9906, 1917, 0, 128001]
+
+
+def test_pretokenize_kats(ctx, oracle):
+    from tokenizer_amd import capi
+    docs = [bytes.fromhex(c["input"]) for c in PRE]
+    text, off = capi.pack_docs(docs)
+    kinds = ctx.pretokenize_batch(text, off)
+    o = off.astype(np.int64)
+    for i, (c, d) in enumerate(zip(PRE, docs)):
+        k = kinds[o[i]:o[i + 1]]
+        starts = np.nonzero(k)[0].tolist()
+        pieces = [d[a:b] for a, b in zip(starts, starts[1:] + [len(d)])]
+        exp = [bytes.fromhex(e) for e in c["expected"]]
+        # expected strings hold U+FFFD for invalid bytes; the KAT inputs are valid UTF-8
+        assert pieces == exp, (c["line"], d)
+
+
+def test_decode_kats(ctx):
+    for case in ENC["decode"]:
+        ids = np.array(case["input"], dtype=np.int64).clip(-2**31, 2**31 - 1).astype(np.int32)
+        out, off = ctx.decode_batch(ids, np.array([0, ids.size], dtype=np.uint64))
+        assert out.tobytes() == bytes.fromhex(case["expected"]), case["line"]
+
+
+def test_special_ids_and_vocab_size(ctx):
+    assert ctx.vocab_size() == 128256
+    assert ctx.special_token_id(b"<|begin_of_text|>") == 128000
+    assert ctx.special_token_id(b"<|end_of_text|>") == 128001
+    assert ctx.special_token_id(b"<|eot_id|>") == 128009
+    assert ctx.special_token_id(b"<|reserved_special_token_247|>") == 128255
+    from tokenizer_amd import capi
+    with pytest.raises(capi.L3Error):
+        ctx.special_token_id(b"<|nope|>")
+
+
+# ---- differential tests against the oracle -----------------------------------------------------------
+def test_boundaries_fuzz(ctx, oracle):
+    from tokenizer_amd import capi
+    rng = random.Random(99)
+    docs = [corpus.random_doc(rng) for _ in range(20000)] + [corpus.random_bytes_doc(rng, rng.randint(0, 40)) for _ in range(2000)]
+    text, off = capi.pack_docs(docs)
+    kinds = ctx.pretokenize_batch(text, off)
+    o = off.astype(np.int64)
+    for i, d in enumerate(docs):
+        st, kd = oracle.split_document(d)
+        k = kinds[o[i]:o[i + 1]]
+        got = np.nonzero(k)[0].tolist()
+        assert got == st and (k[got] - 1).tolist() == kd, (i, d)
+
+
+def test_encode_fuzz_small_docs(ctx, oracle):
+    rng = random.Random(7)
+    docs = [corpus.random_doc(rng) for _ in range(30000)]
+    check_batch(ctx, oracle, docs, True, True, "random pieces")
+    check_batch(ctx, oracle, docs[:5000], False, False, "random pieces, no BOS/EOS")
+    check_batch(ctx, oracle, docs[:5000], True, False, "random pieces, BOS only")
+    check_batch(ctx, oracle, docs[:5000], False, True, "random pieces, EOS only")
+
+
+def test_encode_random_bytes(ctx, oracle):
+    rng = random.Random(8)
+    docs = [corpus.random_bytes_doc(rng, rng.randint(0, 300)) for _ in range(3000)]
+    check_batch(ctx, oracle, docs, True, True, "random bytes")
+
+
+def test_encode_random_words(ctx, oracle):
+    rng = random.Random(9)
+    docs = [b" ".join(corpus.random_word(rng, lo=1, hi=40) for _ in range(rng.randint(1, 30))) for _ in range(4000)]
+    check_batch(ctx, oracle, docs, False, False, "random words")
+
+
+def test_empty_inputs(ctx, oracle):
+    check_batch(ctx, oracle, [], True, True, "no documents")
+    check_batch(ctx, oracle, [b""], True, True, "one empty document")
+    check_batch(ctx, oracle, [b"", b"", b""], True, True, "empty documents")
+    check_batch(ctx, oracle, [b"", b"a", b"", b"", b"b c", b""], True, True, "ragged with empties")
+    check_batch(ctx, oracle, [b"", b"a", b"", b"", b"b c", b""], False, False, "ragged with empties, no BOS/EOS")
+    check_batch(ctx, oracle, [b""] * 5000 + [b"x"] + [b""] * 5000, True, True, "many empties")
+
+
+def test_tile_borders(ctx, oracle):
+    # documents and pre-tokens straddling 4 KiB tile borders in every phase
+    rng = random.Random(10)
+    for shift in range(0, 70, 3):
+        docs = [b"x" * shift] + [corpus.random_doc(rng, max_pieces=40) for _ in range(400)]
+        check_batch(ctx, oracle, docs, True, True, "shift %d" % shift)
+    base = (b"The quick brown fox don't jump over 12345 lazy dogs!!\n\n  " * 200)
+    for cut in (4090, 4095, 4096, 4097, 4100, 8191, 8192, 8193):
+        check_batch(ctx, oracle, [base[:cut], base[cut:]], True, True, "cut %d" % cut)
+    check_batch(ctx, oracle, [base], True, True, "one 11 KB document")
+
+
+def test_long_runs(ctx, oracle):
+    n = 20000
+    docs = [b" " * n, b"\t" * n, b"\n \n " * (n // 4), b"0123456789" * (n // 10), b"a" * n, b"'s" * (n // 2),
+            b"ab" * 3000, b"!" * 7000 + b"\n" * 300, ("٣".encode() * 5000), b"12" + "٣".encode() * 4101 + b"7" * 4099,
+            b"\xff" * 5000, "中".encode() * 3000, ("文字" * 2500).encode(), b"x" * 100 + b" " * 9000 + b"y",
+            b"word " * 4000, b"a" * 64, b"a" * 65, b"a" * 191, b"a" * 192, b"a" * 193, b"a" * 4096, b"a" * 4097]
+    for i, d in enumerate(docs):
+        check_batch(ctx, oracle, [d], True, True, "long run %d" % i)
+    check_batch(ctx, oracle, docs, True, True, "long runs as one batch")
+
+
+def test_special_tokens(ctx, oracle):
+    docs = []
+    for s in corpus.SPECIALS + corpus.NEAR_MISSES:
+        docs += [s, b"x " + s + b"\n y", s[:-1], s + s, b"12" + s + b"34", b" " + s, s + b" "]
+    names = [("<|%s|>" % n).encode() for n in corpora.SPECIAL_NAMES]
+    docs.append(b"".join(names))
+    docs.append(b" ".join(names))
+    docs += names
+    # specials straddling tile borders
+    for k in range(4060, 4100):
+        docs.append(b"a" * k + b"<|begin_of_text|>tail")
+    check_batch(ctx, oracle, docs, True, True, "special tokens")
+    check_batch(ctx, oracle, docs, False, False, "special tokens no BOS/EOS")
+
+
+def test_english_sample(ctx, oracle):
+    text, off = corpora.english(4096, 1024)
+    got_tok, got_off = ctx.encode_batch(text, off, True, True)
+    exp_tok, exp_off = oracle.encode_batch(text, off, True, True, threads=8)
+    assert np.array_equal(got_off, exp_off)
+    assert np.array_equal(got_tok, exp_tok)
+
+
+def test_multilingual_sample(ctx, oracle):
+    text, off = corpora.multilingual(3, 1 << 18)
+    got_tok, got_off = ctx.encode_batch(text, off, True, True)
+    exp_tok, exp_off = oracle.encode_batch(text, off, True, True, threads=3)
+    assert np.array_equal(got_off, exp_off)
+    bad = np.nonzero(got_tok[:exp_tok.size] != exp_tok[:got_tok.size])[0]
+    assert got_tok.size == exp_tok.size and bad.size == 0, (got_tok.size, exp_tok.size, bad[:5])
+
+
+def test_pathological_small(ctx, oracle):
+    docs = corpora.pathological(size=1 << 14)
+    for i, d in enumerate(docs):
+        check_batch(ctx, oracle, [d], True, True, "pathological %d" % i)
+    check_batch(ctx, oracle, docs, True, True, "pathological batch")
+
+
+def test_output_capacity_protocol(ctx):
+    from tokenizer_amd import capi
+    text, off = capi.pack_docs([b"Hello, world!", b"Hello world!"])
+    with pytest.raises(capi.L3Error) as ei:
+        ctx.encode_batch(text, off, True, True, out_cap=3)
+    assert ei.value.code == capi.L3_E_OUTPUT_CAP
+    tok, o = ctx.encode_batch(text, off, True, True, out_cap=11)
+    assert tok.tolist() == [128000, 9906, 11, 1917, 0, 128001, 128000, 9906, 1917, 0, 128001]
+
+
+def test_bad_offsets_rejected(ctx):
+    from tokenizer_amd import capi
+    text = np.frombuffer(b"abcdef", dtype=np.uint8)
+    with pytest.raises(capi.L3Error):
+        ctx.encode_batch(text, np.array([0, 4, 2, 6], dtype=np.uint64))
+    with pytest.raises(capi.L3Error):
+        ctx.encode_batch(text, np.array([1, 6], dtype=np.uint64))
+
+
+def test_device_pointer_api(ctx, oracle):
+    import torch
+    from tokenizer_amd import capi
+    text, off = corpora.english(512, 1024)
+    d_text = torch.from_numpy(text).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    cap = text.size // 2
+    d_out = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_out_off = torch.empty(off.size, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rc, n = ctx.encode_batch_device(d_text.data_ptr(), text.size, d_off.data_ptr(), off.size - 1, 3, d_out.data_ptr(), cap,
+                                    d_out_off.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == capi.L3_OK
+    exp_tok, exp_off = oracle.encode_batch(text, off, True, True, threads=8)
+    assert n == exp_tok.size
+    assert np.array_equal(d_out[:n].cpu().numpy(), exp_tok)
+    assert np.array_equal(d_out_off.cpu().numpy().astype(np.uint64), exp_off)
+    # bad offsets on the device path are caught by the validation kernel, not by a fault
+    bad = d_off.clone(); bad[3] = 10 ** 12
+    rc, _ = ctx.encode_batch_device(d_text.data_ptr(), text.size, bad.data_ptr(), off.size - 1, 3, d_out.data_ptr(), cap,
+                                    d_out_off.data_ptr(), None)
+    assert rc == capi.L3_E_INVALID_ARG
+    # too small an output buffer: error code + required size, nothing else
+    rc, need = ctx.encode_batch_device(d_text.data_ptr(), text.size, d_off.data_ptr(), off.size - 1, 3, d_out.data_ptr(), 10,
+                                       d_out_off.data_ptr(), None)
+    assert rc == capi.L3_E_OUTPUT_CAP and need == exp_tok.size
+
+
+def test_decode_round_trip(ctx, oracle):
+    rng = random.Random(11)
+    docs = [corpus.random_doc(rng, special_rate=0.0) for _ in range(2000)]
+    docs = [d for d in docs if d.decode("utf-8", "ignore").encode() == d]  # valid UTF-8 round-trips exactly
+    from tokenizer_amd import capi
+    text, off = capi.pack_docs(docs)
+    tok, toff = ctx.encode_batch(text, off, False, False)
+    out, ooff = ctx.decode_batch(tok, toff)
+    assert np.array_equal(ooff, off) and out.tobytes() == text.tobytes()
+    ids = np.array([rng.randrange(-5, 128300) for _ in range(5000)], dtype=np.int32)
+    out, ooff = ctx.decode_batch(ids, np.array([0, 100, 100, 5000], dtype=np.uint64))
+    assert out.tobytes() == oracle.decode(ids.tolist())
+    assert int(ooff[1]) == len(oracle.decode(ids[:100].tolist())) and ooff[1] == ooff[2]

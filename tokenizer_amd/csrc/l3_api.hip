@@ -1,0 +1,450 @@
+// l3_api.hip -- the C ABI of libl3hip.so (include/l3hip.h): context, device tables, workspace
+// management and the host-side control of the encode / decode pipelines.  HIP only: there is no
+// CPU fallback, every entry point fails with L3_E_NO_DEVICE / L3_E_HIP when the GPU path is unusable.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/l3hip.h"
+#include "l3_kernels.h"
+#include "l3_tables.h"
+
+using namespace l3;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    // grow-only; contents are NOT preserved
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class U> U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+}  // namespace
+
+struct l3_ctx {
+    int device = 0;
+    HostTables H;
+    Tables T{};
+    DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes;
+    DevBuf w_stream, w_items, w_nslow, w_slow0, w_extra, w_base, w_doc0, w_docitem, w_slow, w_pool, w_scratch, w_status;
+    DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
+    uint64_t slow_cap = 0, pool_cap = 0, scratch_cap = 0;
+    Status* h_status = nullptr;          // pinned
+    unsigned long long* h_total = nullptr;  // pinned
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[kEvCount] = {};
+    bool have_events = false, profiling = false;
+    float last_ms[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t counters[5] = {0, 0, 0, 0, 0};
+    std::unordered_map<std::string, int> special_by_name;
+    std::mutex mu;
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return L3_E_HIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+template <class V>
+int upload(l3_ctx* c, DevBuf& b, const V* src, size_t count) {
+    size_t bytes = count * sizeof(V);
+    HIPCHK(c, b.ensure(bytes ? bytes : 16));
+    if (bytes) HIPCHK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return L3_OK;
+}
+
+int upload_tables(l3_ctx* c) {
+    HostTables& H = c->H;
+    int rc;
+    if ((rc = upload(c, c->t_cls1, H.cls_stage1.data(), H.cls_stage1.size()))) return rc;
+    if ((rc = upload(c, c->t_clsb, H.cls_blocks.data(), H.cls_blocks.size()))) return rc;
+    if ((rc = upload(c, c->t_bytetok, H.byte_tok, 256))) return rc;
+    if ((rc = upload(c, c->t_bytepair, H.bytepair.data(), H.bytepair.size()))) return rc;
+    if ((rc = upload(c, c->t_pairs, H.pair_slots.data(), H.pair_slots.size()))) return rc;
+    if ((rc = upload(c, c->t_vslots, H.vocab_slots.data(), H.vocab_slots.size()))) return rc;
+    if ((rc = upload(c, c->t_vblob, H.vocab_blob.data(), H.vocab_blob.size()))) return rc;
+    if ((rc = upload(c, c->t_special, H.special_id, 256))) return rc;
+    if ((rc = upload(c, c->t_tokoff, H.tok_off.data(), H.tok_off.size()))) return rc;
+    if ((rc = upload(c, c->t_tokbytes, H.tok_bytes.data(), H.tok_bytes.size()))) return rc;
+    Tables& T = c->T;
+    T.cls_stage1 = c->t_cls1.as<uint16_t>();
+    T.cls_blocks = c->t_clsb.as<uint8_t>();
+    T.byte_tok = c->t_bytetok.as<uint8_t>();
+    T.bytepair = c->t_bytepair.as<uint32_t>();
+    T.pair_slots = c->t_pairs.as<uint64_t>();
+    T.vocab_slots = c->t_vslots.as<VocabSlot>();
+    T.vocab_blob = c->t_vblob.as<uint8_t>();
+    T.special_id = c->t_special.as<int32_t>();
+    T.pair_log2 = H.pair_log2;
+    T.vocab_log2 = H.vocab_log2;
+    return L3_OK;
+}
+
+int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W) {
+    const uint64_t n_tiles = num_tiles(n_bytes);
+    HIPCHK(c, c->w_stream.ensure(n_tiles * kTileCap * sizeof(int32_t)));
+    HIPCHK(c, c->w_items.ensure(n_tiles * 4));
+    HIPCHK(c, c->w_nslow.ensure(n_tiles * 4));
+    HIPCHK(c, c->w_slow0.ensure(n_tiles * 4));
+    HIPCHK(c, c->w_extra.ensure(n_tiles * 4));
+    HIPCHK(c, c->w_base.ensure((n_tiles + 1) * 8));
+    HIPCHK(c, c->w_doc0.ensure((n_tiles + 1) * 4));
+    HIPCHK(c, c->w_docitem.ensure((n_docs + 1) * 4));
+    HIPCHK(c, c->w_status.ensure(sizeof(Status)));
+    uint64_t slow_min = n_bytes / 256 + 1024, pool_min = n_bytes / 16 + 4096, scratch_min = 16ull << 20;
+    if (c->slow_cap < slow_min) c->slow_cap = slow_min;
+    if (c->pool_cap < pool_min) c->pool_cap = pool_min;
+    if (c->scratch_cap < scratch_min) c->scratch_cap = scratch_min;
+    HIPCHK(c, c->w_slow.ensure(c->slow_cap * sizeof(SlowEntry)));
+    HIPCHK(c, c->w_pool.ensure(c->pool_cap * sizeof(int32_t)));
+    HIPCHK(c, c->w_scratch.ensure(c->scratch_cap));
+    W.stream = c->w_stream.as<int32_t>();
+    W.tile_items = c->w_items.as<uint32_t>();
+    W.tile_nslow = c->w_nslow.as<uint32_t>();
+    W.tile_slow0 = c->w_slow0.as<uint32_t>();
+    W.tile_extra = c->w_extra.as<uint32_t>();
+    W.tile_base = c->w_base.as<uint64_t>();
+    W.tile_doc0 = c->w_doc0.as<uint32_t>();
+    W.doc_item = c->w_docitem.as<uint32_t>();
+    W.slow = c->w_slow.as<SlowEntry>();
+    W.pool = c->w_pool.as<int32_t>();
+    W.scratch = c->w_scratch.as<uint8_t>();
+    W.status = c->w_status.as<Status>();
+    W.slow_cap = c->slow_cap;
+    W.pool_cap = c->pool_cap;
+    W.scratch_cap = c->scratch_cap;
+    return L3_OK;
+}
+
+// Runs the pipeline on device-resident data.  On L3_OK or L3_E_OUTPUT_CAP *n_tok is the total.
+// `W_out` (optional) receives the workspace used, so a caller can re-run the final scatter.
+int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_tok, Workspace* W_out) {
+    if (A.n_bytes >= (1ull << 40) || A.n_docs >= 0xFFFFFFFEull) {
+        c->err = "batch too large: split it (n_bytes < 2^40, n_docs < 2^32-2)";
+        return L3_E_INVALID_ARG;
+    }
+    const uint64_t n_tiles = num_tiles(A.n_bytes);
+    if (n_tiles > 0x7FFFFFFFull) { c->err = "batch too large: split it"; return L3_E_INVALID_ARG; }
+    c->counters[4] = 0;
+    for (int attempt = 0;; attempt++) {
+        Workspace W{};
+        int rc = ensure_workspace(c, A.n_bytes, A.n_docs, W);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream));
+        HIPCHK(c, hipMemsetAsync(W.tile_extra, 0, n_tiles * 4, stream));
+        HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false));
+        HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
+        HIPCHK(c, hipStreamSynchronize(stream));
+        const Status st = *c->h_status;
+        if (st.flags & kBadOffsets) {
+            c->err = "doc_off must start at 0, be ascending and end at n_bytes";
+            return L3_E_INVALID_ARG;
+        }
+        bool grow = false;
+        if (st.flags & kOvfSlow) { c->slow_cap = (uint64_t)st.slow_count + st.slow_count / 4 + 1024; grow = true; }
+        if (st.flags & kOvfPool) { c->pool_cap = st.pool_used + st.pool_used / 4 + 4096; grow = true; }
+        if (st.flags & kOvfScratch) { c->scratch_cap = st.scratch_used + st.scratch_used / 4 + (1ull << 20); grow = true; }
+        if (grow) {
+            if (attempt >= 8) { c->err = "workspace did not converge"; return L3_E_HIP; }
+            c->counters[4]++;
+            continue;
+        }
+        if (c->profiling) {
+            float total = 0;
+            for (int i = 0; i < 5; i++) {
+                float ms = 0;
+                HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+                c->last_ms[i] = ms;
+            }
+            HIPCHK(c, hipEventElapsedTime(&total, c->ev[kEvStart], c->ev[kEvEmit]));
+            c->last_ms[5] = total;
+        }
+        c->counters[0] = n_tiles;
+        c->counters[1] = st.slow_count;
+        c->counters[2] = st.pool_used;
+        c->counters[3] = st.scratch_used;
+        *n_tok = st.total_tokens;
+        if (W_out) *W_out = W;
+        return (st.flags & kOvfOut) ? L3_E_OUTPUT_CAP : L3_OK;
+    }
+}
+
+int check_offsets_host(l3_ctx* c, const uint64_t* off, uint64_t n) {
+    if (off[0] != 0) { c->err = "offsets must start at 0"; return L3_E_INVALID_ARG; }
+    for (uint64_t i = 0; i < n; i++)
+        if (off[i + 1] < off[i]) { c->err = "offsets must be ascending"; return L3_E_INVALID_ARG; }
+    return L3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int l3_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len, int device,
+              l3_ctx** out) {
+    if (!out) return L3_E_INVALID_ARG;
+    *out = nullptr;
+    if (!vocab_b64 || !merges_b64) { g_create_err = "null data pointer"; return L3_E_INVALID_ARG; }
+    l3_ctx* c = new l3_ctx();
+    if (!build_tables(vocab_b64, vocab_len, merges_b64, merges_len, c->H)) {
+        g_create_err = c->H.error;
+        delete c;
+        return L3_E_DATA;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_create_err = "no usable HIP device (there is no CPU fallback)";
+        delete c;
+        return L3_E_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_err = std::string("device is not gfx950 (MI355X): ") + prop.gcnArchName;
+        delete c;
+        return L3_E_NO_DEVICE;
+    }
+    c->device = device;
+    auto fail = [&](int rc) {
+        g_create_err = c->err;
+        l3_destroy(c);
+        return rc;
+    };
+    if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(L3_E_HIP); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(L3_E_HIP); }
+    for (int i = 0; i < kEvCount; i++)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(L3_E_HIP); }
+    c->have_events = true;
+    if (hipHostMalloc((void**)&c->h_status, sizeof(Status), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_total, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        c->err = "hipHostMalloc failed";
+        return fail(L3_E_HIP);
+    }
+    int rc = upload_tables(c);
+    if (rc) return fail(rc);
+    for (int i = 0; i < kNumSpecial; i++) c->special_by_name[special_name(i)] = c->H.special_id[i];
+    *out = c;
+    return L3_OK;
+}
+
+void l3_destroy(l3_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
+                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_stream, &c->w_items, &c->w_nslow, &c->w_slow0,
+                      &c->w_extra, &c->w_base, &c->w_doc0, &c->w_docitem, &c->w_slow, &c->w_pool, &c->w_scratch,
+                      &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
+                      &c->s_total};
+    for (DevBuf* b : bufs) b->release();
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->have_events)
+        for (int i = 0; i < kEvCount; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* l3_last_error(const l3_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int l3_encode_batch_device(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off,
+                           uint64_t n_docs, uint32_t flags, int32_t* d_out_tok, uint64_t out_cap,
+                           uint64_t* d_out_off, uint64_t* n_tok, void* stream) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!d_doc_off || !d_out_off || !n_tok || (!d_text && n_bytes) || (!d_out_tok && out_cap)) {
+        c->err = "null pointer argument";
+        return L3_E_INVALID_ARG;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    EncodeArgs A{};
+    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = flags;
+    A.out_tok = d_out_tok; A.out_cap = out_cap; A.out_off = d_out_off; A.kinds = nullptr;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    int rc = encode_core(c, A, s, n_tok, nullptr);
+    if (rc == L3_E_OUTPUT_CAP) c->err = "output buffer too small";
+    return rc;
+}
+
+int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                    int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!doc_off || !out_off || !n_tok || (!out_tok && out_cap)) { c->err = "null pointer argument"; return L3_E_INVALID_ARG; }
+    int rc = check_offsets_host(c, doc_off, n_docs);
+    if (rc) return rc;
+    const uint64_t n_bytes = doc_off[n_docs];
+    if (!text && n_bytes) { c->err = "null text"; return L3_E_INVALID_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c, c->s_text.ensure(n_bytes + 16));
+    HIPCHK(c, c->s_off.ensure((n_docs + 1) * 8));
+    HIPCHK(c, c->s_outoff.ensure((n_docs + 1) * 8));
+    uint64_t guess = n_bytes / 3 + 2 * n_docs + 1024;
+    HIPCHK(c, c->s_out.ensure(guess * 4));
+    if (n_bytes) HIPCHK(c, hipMemcpyAsync(c->s_text.p, text, n_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->s_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    EncodeArgs A{};
+    A.text = c->s_text.as<uint8_t>(); A.n_bytes = n_bytes; A.doc_off = c->s_off.as<uint64_t>(); A.n_docs = n_docs;
+    A.flags = flags; A.out_tok = c->s_out.as<int32_t>(); A.out_cap = c->s_out.cap / 4;
+    A.out_off = c->s_outoff.as<uint64_t>(); A.kinds = nullptr;
+    Workspace W{};
+    uint64_t total = 0;
+    rc = encode_core(c, A, s, &total, &W);
+    if (rc == L3_E_OUTPUT_CAP) {  // our guess was too small: enlarge and redo only the final scatter
+        HIPCHK(c, c->s_out.ensure(total * 4));
+        A.out_tok = c->s_out.as<int32_t>();
+        A.out_cap = c->s_out.cap / 4;
+        HIPCHK(c, launch_encode(c->T, W, A, s, nullptr, true));
+        rc = L3_OK;
+    }
+    if (rc) return rc;
+    *n_tok = total;
+    HIPCHK(c, hipMemcpyAsync(out_off, c->s_outoff.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (total > out_cap) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->err = "output buffer too small";
+        return L3_E_OUTPUT_CAP;
+    }
+    if (total) HIPCHK(c, hipMemcpyAsync(out_tok, c->s_out.p, total * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return L3_OK;
+}
+
+int l3_pretokenize_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint8_t* kinds) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!doc_off) { c->err = "null pointer argument"; return L3_E_INVALID_ARG; }
+    int rc = check_offsets_host(c, doc_off, n_docs);
+    if (rc) return rc;
+    const uint64_t n_bytes = doc_off[n_docs];
+    if ((!text || !kinds) && n_bytes) { c->err = "null pointer argument"; return L3_E_INVALID_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c, c->s_text.ensure(n_bytes + 16));
+    HIPCHK(c, c->s_off.ensure((n_docs + 1) * 8));
+    HIPCHK(c, c->s_outoff.ensure((n_docs + 1) * 8));
+    HIPCHK(c, c->s_kinds.ensure(n_bytes + 16));
+    HIPCHK(c, c->s_out.ensure(16));
+    if (n_bytes) HIPCHK(c, hipMemcpyAsync(c->s_text.p, text, n_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->s_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    EncodeArgs A{};
+    A.text = c->s_text.as<uint8_t>(); A.n_bytes = n_bytes; A.doc_off = c->s_off.as<uint64_t>(); A.n_docs = n_docs;
+    A.flags = 0; A.out_tok = c->s_out.as<int32_t>(); A.out_cap = 0;  // boundaries only: the scatter is skipped
+    A.out_off = c->s_outoff.as<uint64_t>(); A.kinds = c->s_kinds.as<uint8_t>();
+    uint64_t total = 0;
+    rc = encode_core(c, A, s, &total, nullptr);
+    if (rc != L3_OK && rc != L3_E_OUTPUT_CAP) return rc;
+    if (n_bytes) HIPCHK(c, hipMemcpyAsync(kinds, c->s_kinds.p, n_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return L3_OK;
+}
+
+int l3_decode_batch(l3_ctx* c, const int32_t* ids, const uint64_t* id_off, uint64_t n_seqs, uint8_t* out_bytes,
+                    uint64_t out_cap, uint64_t* out_off, uint64_t* n_bytes) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!id_off || !out_off || !n_bytes || (!out_bytes && out_cap)) { c->err = "null pointer argument"; return L3_E_INVALID_ARG; }
+    int rc = check_offsets_host(c, id_off, n_seqs);
+    if (rc) return rc;
+    const uint64_t n_ids = id_off[n_seqs];
+    if (!ids && n_ids) { c->err = "null ids"; return L3_E_INVALID_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c, c->s_ids.ensure(n_ids * 4 + 16));
+    HIPCHK(c, c->s_idoff.ensure((n_seqs + 1) * 8));
+    HIPCHK(c, c->s_outoff.ensure((n_seqs + 1) * 8));
+    HIPCHK(c, c->s_total.ensure(16));
+    // every id decodes to at most kMaxTokenBytes bytes; start from a typical size and retry once
+    uint64_t guess = n_ids * 6 + 1024;
+    HIPCHK(c, c->s_kinds.ensure(guess));
+    if (n_ids) HIPCHK(c, hipMemcpyAsync(c->s_ids.p, ids, n_ids * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->s_idoff.p, id_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, s));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIPCHK(c, launch_decode(c->t_tokoff.as<uint32_t>(), c->t_tokbytes.as<uint8_t>(), c->H.n_tokens,
+                                c->s_ids.as<int32_t>(), c->s_idoff.as<uint64_t>(), n_seqs, c->s_kinds.as<uint8_t>(),
+                                c->s_kinds.cap, c->s_outoff.as<uint64_t>(), c->s_total.as<unsigned long long>(), s));
+        HIPCHK(c, hipMemcpyAsync(c->h_total, c->s_total.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (*c->h_total <= c->s_kinds.cap) break;
+        HIPCHK(c, c->s_kinds.ensure(*c->h_total));
+    }
+    const uint64_t total = *c->h_total;
+    *n_bytes = total;
+    HIPCHK(c, hipMemcpyAsync(out_off, c->s_outoff.p, (n_seqs + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (total > out_cap) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->err = "output buffer too small";
+        return L3_E_OUTPUT_CAP;
+    }
+    if (total) HIPCHK(c, hipMemcpyAsync(out_bytes, c->s_kinds.p, total, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return L3_OK;
+}
+
+int l3_special_token_id(const l3_ctx* c, const char* name, size_t name_len, int32_t* id) {
+    if (!c || !name || !id) return L3_E_INVALID_ARG;
+    auto it = c->special_by_name.find(std::string(name, name_len));
+    if (it == c->special_by_name.end()) return L3_E_NOT_FOUND;
+    *id = it->second;
+    return L3_OK;
+}
+
+int l3_vocab_size(const l3_ctx* c) { return c ? c->H.n_tokens : L3_E_INVALID_ARG; }
+
+int l3_token_bytes(const l3_ctx* c, int32_t id, uint8_t* out, size_t cap) {
+    if (!c) return L3_E_INVALID_ARG;
+    if (id < 0 || id >= c->H.n_tokens) return L3_E_NOT_FOUND;
+    uint32_t a = c->H.tok_off[id], b = c->H.tok_off[id + 1];
+    size_t l = b - a;
+    if (out && cap) memcpy(out, c->H.tok_bytes.data() + a, l < cap ? l : cap);
+    return (int)l;
+}
+
+int l3_set_profiling(l3_ctx* c, int enabled) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->profiling = enabled != 0;
+    return L3_OK;
+}
+
+int l3_last_timings(l3_ctx* c, float* ms, int cap) {
+    if (!c || !ms) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int n = cap < 6 ? cap : 6;
+    for (int i = 0; i < n; i++) ms[i] = c->last_ms[i];
+    return n;
+}
+
+int l3_last_counters(l3_ctx* c, uint64_t* out, int cap) {
+    if (!c || !out) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int n = cap < 5 ? cap : 5;
+    for (int i = 0; i < n; i++) out[i] = c->counters[i];
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// l3_kernels.h -- launch interface of the HIP kernels (l3_kernels.hip) used by the C ABI (l3_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "l3_common.h"
+
+namespace l3 {
+
+// ---- geometry of the tile kernel -----------------------------------------------------------------
+constexpr int kTile = 4096;       // bytes of text owned by one workgroup
+constexpr int kBack = 64;         // look-behind halo (special token 30 B + 4 runes 16 B + slack)
+constexpr int kFwd = 192;         // look-ahead halo
+constexpr int kRegion = kBack + kTile + kFwd;
+constexpr int kEvalSlack = 36;    // positions closer than this to a soft region end cannot be decided
+constexpr int kLaneMax = 64;      // longest pre-token (bytes) merged by a single lane in the tile kernel
+constexpr int kTileCap = kTile + kLaneMax;  // stream items one tile can emit (one per byte at most)
+constexpr int kTileThreads = 256;
+constexpr int kSlowThreads = 256;
+constexpr int kSlowLds = 3072;    // symbols of a slow pre-token merged in LDS; longer ones use HBM scratch
+
+// stream item markers
+constexpr int32_t kDead = -1;
+constexpr int32_t kSlowMark = -2;   // placeholder of a pre-token handled by the slow kernel
+constexpr int32_t kMissMark = -3;   // (tile kernel internal) pre-token waiting for the in-lane merge
+
+// A pre-token the tile kernel does not finish itself: it contains invalid UTF-8 (its symbols are
+// not its bytes), is longer than kLaneMax without being a vocabulary entry, or ends past the halo.
+struct SlowEntry {
+    uint64_t start;      // global byte offset of its first byte
+    uint64_t scan_from;  // len == 0: first position the tile kernel could not decide
+    uint32_t len;        // source bytes, 0 = unknown (ends beyond the tile's look-ahead)
+    uint32_t tile;       // owning tile
+    uint32_t count;      // tokens produced (written by the slow kernel)
+    uint32_t pad;
+    uint64_t pool_off;   // first token in the slow pool (written by the slow kernel)
+};
+
+// status word written by the kernels (device memory, zeroed per call)
+enum : uint32_t {
+    kOvfSlow = 1,      // more slow entries than slow_cap
+    kOvfPool = 2,      // slow pool too small
+    kOvfOut = 4,       // out_cap too small (total_tokens holds the need)
+    kBadOffsets = 8,   // doc_off is not ascending / does not start at 0 / does not end at n_bytes
+    kOvfScratch = 16,  // giant pre-token scratch too small
+};
+struct Status {
+    uint32_t slow_count;        // entries appended so far (may exceed capacity: overflow)
+    uint32_t flags;             // kOvf* / kBadOffsets
+    unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
+    unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the scan)
+    unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)
+};
+
+struct Workspace {
+    int32_t* stream;        // [n_tiles * kTileCap] per-tile token stream incl. slow placeholders
+    uint32_t* tile_items;   // [n_tiles] items in the tile's stream
+    uint32_t* tile_nslow;   // [n_tiles] placeholders among them
+    uint32_t* tile_slow0;   // [n_tiles] index of the tile's first slow entry
+    uint32_t* tile_extra;   // [n_tiles] tokens produced by the tile's slow entries (atomic adds)
+    uint64_t* tile_base;    // [n_tiles + 1] exclusive scan of the tile token totals
+    uint32_t* tile_doc0;    // [n_tiles + 1] first document whose start is >= the tile start
+    uint32_t* doc_item;     // [n_docs + 1] stream index (inside its tile) of the document's first item
+    SlowEntry* slow;        // [slow_cap]
+    int32_t* pool;          // [pool_cap] tokens of slow pre-tokens
+    uint8_t* scratch;       // [scratch_cap] symbol arrays of pre-tokens too long for LDS
+    Status* status;
+    uint64_t slow_cap, pool_cap, scratch_cap;
+};
+
+struct EncodeArgs {
+    const uint8_t* text;      // device
+    uint64_t n_bytes;
+    const uint64_t* doc_off;  // device, n_docs + 1 ascending offsets, doc_off[0] = 0, doc_off[n_docs] = n_bytes
+    uint64_t n_docs;
+    uint32_t flags;           // bit0 BOS, bit1 EOS
+    int32_t* out_tok;         // device
+    uint64_t out_cap;
+    uint64_t* out_off;        // device, n_docs + 1
+    uint8_t* kinds;           // optional (pre-tokenize API): one byte per text byte, 1 = pre-token start,
+                              // 2 = special-token start, 0 otherwise
+};
+
+inline uint64_t num_tiles(uint64_t n_bytes) { return n_bytes == 0 ? 1 : (n_bytes + kTile - 1) / kTile; }
+
+enum { kEvStart = 0, kEvDocs, kEvTile, kEvSlow, kEvScan, kEvEmit, kEvCount };
+
+// Enqueue the encode pipeline on `stream`; nothing is synchronised.  `ev` (optional, kEvCount
+// events) are recorded between the kernels.  `emit_only` re-runs just the final scatter (after
+// the caller enlarged the output buffer).
+hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream,
+                         hipEvent_t* ev, bool emit_only);
+// Decode: ids -> bytes (tokenizer.go:339-354).  Two passes: lengths+scan, then copy.
+hipError_t launch_decode(const uint32_t* tok_off, const uint8_t* tok_bytes, int n_tokens, const int32_t* ids,
+                         const uint64_t* id_off, uint64_t n_seqs, uint8_t* out, uint64_t out_cap,
+                         uint64_t* out_off, unsigned long long* total, hipStream_t stream);
+
+}  // namespace l3
