@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace 
         if (q < own_lo || q >= eval_hi) continue;
         uint32_t w = R.a[q];
         if (!(w & I_RUNE) || (w & I_SPBODY)) continue;
-        if (starts_pretoken(src, q, (int)((w >> I_DOFF_SHIFT) & 3u))) {
+        if ((A.flags & 0x400u) ? ((w & I_CLS) >= C_SP || (w & I_SEG)) : starts_pretoken(src, q, (int)((w >> I_DOFF_SHIFT) & 3u))) {
             mymask |= 1u << j;
             if (q < own_hi) ownmask |= 1u << j;
         }
@@ -438,7 +438,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace 
         uint32_t inval = 0;
         for (int q = s; q < e; q++) inval |= R.a[q] & I_INVALID;
         int32_t id = -1;
-        if (!inval && len <= kMaxTokenBytes) id = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)R.b[s + i]; }, (uint32_t)len);
+        if (A.flags & 0x200u) id = 1;
+        else if (!inval && len <= kMaxTokenBytes) id = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)R.b[s + i]; }, (uint32_t)len);
         if (id >= 0) {
             R.a[s] = (uint32_t)id;
             for (int q = s + 1; q < e; q++) R.a[q] = (uint32_t)kDead;
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace 
                 sym[q] = T.byte_tok[b0];
                 pr[q] = (q + 1 < e) ? T.bytepair[(b0 << 8) | R.b[q + 1]] : kNoPrio;
             }
-            merge_span(T, sym, pr, s, e);
+            if (!(A.flags & 0x100u)) merge_span(T, sym, pr, s, e);
         }
     }
     __syncthreads();

@@ -1,0 +1,17 @@
+"""Timing experiment: tile-kernel time with phases disabled through debug flag bits (results are then wrong)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tokenizer_amd import capi
+from tools import corpora
+ctx = capi.Context(0)
+n_docs = 65536
+text, off = corpora.english(n_docs, 1024)
+d_text = torch.from_numpy(text).cuda(); d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+cap = text.size
+d_out = torch.empty(cap, dtype=torch.int32, device="cuda"); d_oo = torch.empty(n_docs + 1, dtype=torch.int64, device="cuda")
+ctx.set_profiling(True)
+for name, fl in [("full", 3), ("no-merge", 3 | 0x100), ("no-merge,no-vocab", 3 | 0x300), ("no-merge,no-vocab,no-starts", 3 | 0x700)]:
+    for _ in range(3):
+        rc, n = ctx.encode_batch_device(d_text.data_ptr(), text.size, d_off.data_ptr(), n_docs, fl, d_out.data_ptr(), cap, d_oo.data_ptr(), None)
+    print(name, rc, n, ctx.last_timings())
