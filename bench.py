@@ -93,7 +93,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     n_tok = 0
-    kern = {"docs": 0.0, "tile": 0.0, "slow": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
+    kern = {"docs": 0.0, "tile": 0.0, "merge": 0.0, "slow": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
     for _ in range(args.steps):
         n_tok = step()
         tm = ctx.last_timings()  # HIP events recorded on the launch stream around every kernel of this call
@@ -120,7 +120,7 @@ def main():
         value = tot_tok * args.steps / dt
         # algorithmic bytes of one launch: input read once + int32 ids written once + uint64 offsets
         b_alg = n_bytes + 4 * n_tok + 8 * (n_docs + 1)
-        dom = max(("tile", "slow", "emit", "scan", "docs"), key=lambda k: kern[k])
+        dom = max(("tile", "merge", "slow", "emit", "scan", "docs"), key=lambda k: kern[k])
         achieved = b_alg / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
         pipeline = b_alg / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
         result = {
@@ -132,7 +132,7 @@ def main():
                        "docs_per_gpu": n_docs, "doc_bytes": DOC_BYTES, "parallelism": "dp%d (documents sharded, no data-path collective)" % world},
             "input_gb_per_s": tot_bytes * args.steps / dt / 1e9,
             "tokens_per_step": tot_tok, "bytes_per_token": tot_bytes / max(tot_tok - 2 * n_docs * world, 1),
-            "kernel_ms": kern, "deferred_pretokens": counters["slow_pretokens"],
+            "kernel_ms": kern, "deferred_pretokens": {"short": counters["short_pretokens"], "slow": counters["slow_pretokens"]},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": b_alg, "kernel_avg_ms": kern[dom],

@@ -76,12 +76,12 @@ int l3_token_bytes(const l3_ctx* ctx, int32_t id, uint8_t* out, size_t cap);
 
 /* Measurement support (no counterpart in the reference): when enabled, HIP events are recorded on the
  * launch stream between the kernels of every encode call; l3_last_timings() returns the milliseconds of
- * the last call: [0] validate+docs, [1] tile kernel, [2] slow kernel, [3] scan, [4] emit, [5] first
- * kernel start -> last kernel end.  Returns the number of values written. */
+ * the last call: [0] validate+docs, [1] tile kernel, [2] merge kernel, [3] slow kernel, [4] scan, [5] emit,
+ * [6] first kernel start -> last kernel end.  Returns the number of values written. */
 int l3_set_profiling(l3_ctx* ctx, int enabled);
 int l3_last_timings(l3_ctx* ctx, float* ms, int cap);
-/* counters of the last encode call: [0] tiles, [1] deferred (slow) pre-tokens, [2] tokens from them,
- * [3] scratch bytes, [4] retries after a workspace grew */
+/* counters of the last encode call: [0] tiles, [1] deferred (slow) pre-tokens, [2] tokens of all
+ * deferred pre-tokens, [3] scratch bytes, [4] retries after a workspace grew, [5] short deferred pre-tokens */
 int l3_last_counters(l3_ctx* ctx, uint64_t* out, int cap);
 
 #ifdef __cplusplus

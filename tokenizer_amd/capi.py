@@ -126,7 +126,7 @@ class Context:
         doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
         n_docs = doc_off.size - 1
         flags = (L3_BOS if bos else 0) | (L3_EOS if eos else 0)
-        cap = int(out_cap) if out_cap is not None else int(text.size) // 2 + 2 * n_docs + 64
+        cap = int(out_cap) if out_cap is not None else int(text.size) + 2 * n_docs + 64  # enough unless bytes are invalid UTF-8
         while True:
             out = np.empty(max(cap, 1), dtype=np.int32)
             off = np.empty(n_docs + 1, dtype=np.uint64)
@@ -203,11 +203,11 @@ class Context:
         self.lib.l3_set_profiling(self.h, int(on))
 
     def last_timings(self):
-        a = np.zeros(6, dtype=np.float32)
-        self.lib.l3_last_timings(self.h, a.ctypes.data, 6)
-        return dict(zip(["docs", "tile", "slow", "scan", "emit", "total"], a.tolist()))
+        a = np.zeros(7, dtype=np.float32)
+        self.lib.l3_last_timings(self.h, a.ctypes.data, 7)
+        return dict(zip(["docs", "tile", "merge", "slow", "scan", "emit", "total"], a.tolist()))
 
     def last_counters(self):
-        a = np.zeros(5, dtype=np.uint64)
-        self.lib.l3_last_counters(self.h, a.ctypes.data, 5)
-        return dict(zip(["tiles", "slow_pretokens", "slow_tokens", "scratch_bytes", "retries"], a.tolist()))
+        a = np.zeros(6, dtype=np.uint64)
+        self.lib.l3_last_counters(self.h, a.ctypes.data, 6)
+        return dict(zip(["tiles", "slow_pretokens", "deferred_tokens", "scratch_bytes", "retries", "short_pretokens"], a.tolist()))

@@ -43,16 +43,16 @@ struct l3_ctx {
     HostTables H;
     Tables T{};
     DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes;
-    DevBuf w_stream, w_items, w_nslow, w_slow0, w_extra, w_base, w_doc0, w_docitem, w_slow, w_pool, w_scratch, w_status;
+    DevBuf w_stream, w_items, w_extra, w_base, w_doc0, w_docitem, w_slow, w_miss, w_pool, w_scratch, w_status;
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
-    uint64_t slow_cap = 0, pool_cap = 0, scratch_cap = 0;
+    uint64_t slow_cap = 0, miss_cap = 0, pool_cap = 0, scratch_cap = 0;
     Status* h_status = nullptr;          // pinned
     unsigned long long* h_total = nullptr;  // pinned
     hipStream_t stream = nullptr;
     hipEvent_t ev[kEvCount] = {};
     bool have_events = false, profiling = false;
-    float last_ms[6] = {0, 0, 0, 0, 0, 0};
-    uint64_t counters[5] = {0, 0, 0, 0, 0};
+    float last_ms[kEvCount] = {};
+    uint64_t counters[6] = {0, 0, 0, 0, 0, 0};
     std::unordered_map<std::string, int> special_by_name;
     std::mutex mu;
     std::string err;
@@ -84,7 +84,7 @@ int upload_tables(l3_ctx* c) {
     if ((rc = upload(c, c->t_clsb, H.cls_blocks.data(), H.cls_blocks.size()))) return rc;
     if ((rc = upload(c, c->t_bytetok, H.byte_tok, 256))) return rc;
     if ((rc = upload(c, c->t_bytepair, H.bytepair.data(), H.bytepair.size()))) return rc;
-    if ((rc = upload(c, c->t_pairs, H.pair_slots.data(), H.pair_slots.size()))) return rc;
+    if ((rc = upload(c, c->t_pairs, H.pair_buckets.data(), H.pair_buckets.size()))) return rc;
     if ((rc = upload(c, c->t_vslots, H.vocab_slots.data(), H.vocab_slots.size()))) return rc;
     if ((rc = upload(c, c->t_vblob, H.vocab_blob.data(), H.vocab_blob.size()))) return rc;
     if ((rc = upload(c, c->t_special, H.special_id, 256))) return rc;
@@ -95,7 +95,7 @@ int upload_tables(l3_ctx* c) {
     T.cls_blocks = c->t_clsb.as<uint8_t>();
     T.byte_tok = c->t_bytetok.as<uint8_t>();
     T.bytepair = c->t_bytepair.as<uint32_t>();
-    T.pair_slots = c->t_pairs.as<uint64_t>();
+    T.pair_buckets = c->t_pairs.as<PairBucket>();
     T.vocab_slots = c->t_vslots.as<VocabSlot>();
     T.vocab_blob = c->t_vblob.as<uint8_t>();
     T.special_id = c->t_special.as<int32_t>();
@@ -108,29 +108,30 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     const uint64_t n_tiles = num_tiles(n_bytes);
     HIPCHK(c, c->w_stream.ensure(n_tiles * kTileCap * sizeof(int32_t)));
     HIPCHK(c, c->w_items.ensure(n_tiles * 4));
-    HIPCHK(c, c->w_nslow.ensure(n_tiles * 4));
-    HIPCHK(c, c->w_slow0.ensure(n_tiles * 4));
     HIPCHK(c, c->w_extra.ensure(n_tiles * 4));
     HIPCHK(c, c->w_base.ensure((n_tiles + 1) * 8));
     HIPCHK(c, c->w_doc0.ensure((n_tiles + 1) * 4));
     HIPCHK(c, c->w_docitem.ensure((n_docs + 1) * 4));
     HIPCHK(c, c->w_status.ensure(sizeof(Status)));
-    uint64_t slow_min = n_bytes / 256 + 1024, pool_min = n_bytes / 16 + 4096, scratch_min = 16ull << 20;
+    uint64_t slow_min = n_bytes / 256 + 1024, miss_min = n_bytes / 64 + 1024, pool_min = n_bytes / 8 + 4096,
+             scratch_min = 16ull << 20;
     if (c->slow_cap < slow_min) c->slow_cap = slow_min;
+    if (c->miss_cap < miss_min) c->miss_cap = miss_min;
     if (c->pool_cap < pool_min) c->pool_cap = pool_min;
     if (c->scratch_cap < scratch_min) c->scratch_cap = scratch_min;
     HIPCHK(c, c->w_slow.ensure(c->slow_cap * sizeof(SlowEntry)));
+    HIPCHK(c, c->w_miss.ensure(c->miss_cap * sizeof(SlowEntry)));
     HIPCHK(c, c->w_pool.ensure(c->pool_cap * sizeof(int32_t)));
     HIPCHK(c, c->w_scratch.ensure(c->scratch_cap));
     W.stream = c->w_stream.as<int32_t>();
     W.tile_items = c->w_items.as<uint32_t>();
-    W.tile_nslow = c->w_nslow.as<uint32_t>();
-    W.tile_slow0 = c->w_slow0.as<uint32_t>();
     W.tile_extra = c->w_extra.as<uint32_t>();
     W.tile_base = c->w_base.as<uint64_t>();
     W.tile_doc0 = c->w_doc0.as<uint32_t>();
     W.doc_item = c->w_docitem.as<uint32_t>();
     W.slow = c->w_slow.as<SlowEntry>();
+    W.miss = c->w_miss.as<SlowEntry>();
+    W.miss_cap = c->miss_cap;
     W.pool = c->w_pool.as<int32_t>();
     W.scratch = c->w_scratch.as<uint8_t>();
     W.status = c->w_status.as<Status>();
@@ -166,6 +167,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         }
         bool grow = false;
         if (st.flags & kOvfSlow) { c->slow_cap = (uint64_t)st.slow_count + st.slow_count / 4 + 1024; grow = true; }
+        if (st.flags & kOvfMiss) { c->miss_cap = (uint64_t)st.miss_count + st.miss_count / 4 + 1024; grow = true; }
         if (st.flags & kOvfPool) { c->pool_cap = st.pool_used + st.pool_used / 4 + 4096; grow = true; }
         if (st.flags & kOvfScratch) { c->scratch_cap = st.scratch_used + st.scratch_used / 4 + (1ull << 20); grow = true; }
         if (grow) {
@@ -175,18 +177,19 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         }
         if (c->profiling) {
             float total = 0;
-            for (int i = 0; i < 5; i++) {
+            for (int i = 0; i + 1 < kEvCount; i++) {
                 float ms = 0;
                 HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
                 c->last_ms[i] = ms;
             }
             HIPCHK(c, hipEventElapsedTime(&total, c->ev[kEvStart], c->ev[kEvEmit]));
-            c->last_ms[5] = total;
+            c->last_ms[kEvCount - 1] = total;
         }
         c->counters[0] = n_tiles;
         c->counters[1] = st.slow_count;
         c->counters[2] = st.pool_used;
         c->counters[3] = st.scratch_used;
+        c->counters[5] = st.miss_count;
         *n_tok = st.total_tokens;
         if (W_out) *W_out = W;
         return (st.flags & kOvfOut) ? L3_E_OUTPUT_CAP : L3_OK;
@@ -255,7 +258,7 @@ void l3_destroy(l3_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
-                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_stream, &c->w_items, &c->w_nslow, &c->w_slow0,
+                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_stream, &c->w_items, &c->w_miss,
                       &c->w_extra, &c->w_base, &c->w_doc0, &c->w_docitem, &c->w_slow, &c->w_pool, &c->w_scratch,
                       &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
                       &c->s_total};
@@ -434,7 +437,7 @@ int l3_set_profiling(l3_ctx* c, int enabled) {
 int l3_last_timings(l3_ctx* c, float* ms, int cap) {
     if (!c || !ms) return L3_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
-    int n = cap < 6 ? cap : 6;
+    int n = cap < kEvCount ? cap : kEvCount;
     for (int i = 0; i < n; i++) ms[i] = c->last_ms[i];
     return n;
 }
@@ -442,7 +445,7 @@ int l3_last_timings(l3_ctx* c, float* ms, int cap) {
 int l3_last_counters(l3_ctx* c, uint64_t* out, int cap) {
     if (!c || !out) return L3_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
-    int n = cap < 5 ? cap : 5;
+    int n = cap < 6 ? cap : 6;
     for (int i = 0; i < n; i++) out[i] = c->counters[i];
     return n;
 }

@@ -42,7 +42,7 @@ void* l3t_create(const void* vocab, size_t vlen, const void* merges, size_t mlen
     h->T.cls_blocks = h->H.cls_blocks.data();
     h->T.byte_tok = h->H.byte_tok;
     h->T.bytepair = h->H.bytepair.data();
-    h->T.pair_slots = h->H.pair_slots.data();
+    h->T.pair_buckets = h->H.pair_buckets.data();
     h->T.vocab_slots = h->H.vocab_slots.data();
     h->T.vocab_blob = h->H.vocab_blob.data();
     h->T.special_id = h->H.special_id;

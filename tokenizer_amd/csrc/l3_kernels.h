@@ -8,21 +8,22 @@
 namespace l3 {
 
 // ---- geometry of the tile kernel -----------------------------------------------------------------
-constexpr int kTile = 4096;       // bytes of text owned by one workgroup
+constexpr int kTile = 2048;       // bytes of text owned by one workgroup
 constexpr int kBack = 64;         // look-behind halo (special token 30 B + 4 runes 16 B + slack)
 constexpr int kFwd = 192;         // look-ahead halo
 constexpr int kRegion = kBack + kTile + kFwd;
 constexpr int kEvalSlack = 36;    // positions closer than this to a soft region end cannot be decided
 constexpr int kLaneMax = 64;      // longest pre-token (bytes) merged by a single lane in the tile kernel
-constexpr int kTileCap = kTile + kLaneMax;  // stream items one tile can emit (one per byte at most)
+constexpr int kTileCap = kTile;  // stream items one tile can emit: one per pre-token that starts in it
 constexpr int kTileThreads = 256;
 constexpr int kSlowThreads = 256;
 constexpr int kSlowLds = 3072;    // symbols of a slow pre-token merged in LDS; longer ones use HBM scratch
 
-// stream item markers
+// A stream item is a token id (>= 0) or the placeholder -2 - e of a deferred pre-token: e < kSlowBase
+// is an index into Workspace::miss (short: merged one lane each by merge_kernel), e >= kSlowBase is
+// kSlowBase + an index into Workspace::slow (long / invalid UTF-8 / open-ended: slow_kernel).
 constexpr int32_t kDead = -1;
-constexpr int32_t kSlowMark = -2;   // placeholder of a pre-token handled by the slow kernel
-constexpr int32_t kMissMark = -3;   // (tile kernel internal) pre-token waiting for the in-lane merge
+constexpr uint32_t kSlowBase = 1u << 30;
 
 // A pre-token the tile kernel does not finish itself: it contains invalid UTF-8 (its symbols are
 // not its bytes), is longer than kLaneMax without being a vocabulary entry, or ends past the halo.
@@ -43,10 +44,13 @@ enum : uint32_t {
     kOvfOut = 4,       // out_cap too small (total_tokens holds the need)
     kBadOffsets = 8,   // doc_off is not ascending / does not start at 0 / does not end at n_bytes
     kOvfScratch = 16,  // giant pre-token scratch too small
+    kOvfMiss = 32,     // more short deferred pre-tokens than miss_cap
 };
 struct Status {
     uint32_t slow_count;        // entries appended so far (may exceed capacity: overflow)
     uint32_t flags;             // kOvf* / kBadOffsets
+    uint32_t miss_count;        // short entries appended so far (may exceed capacity: overflow)
+    uint32_t pad;
     unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
     unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the scan)
     unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)
@@ -55,17 +59,16 @@ struct Status {
 struct Workspace {
     int32_t* stream;        // [n_tiles * kTileCap] per-tile token stream incl. slow placeholders
     uint32_t* tile_items;   // [n_tiles] items in the tile's stream
-    uint32_t* tile_nslow;   // [n_tiles] placeholders among them
-    uint32_t* tile_slow0;   // [n_tiles] index of the tile's first slow entry
-    uint32_t* tile_extra;   // [n_tiles] tokens produced by the tile's slow entries (atomic adds)
+    uint32_t* tile_extra;   // [n_tiles] sum of (tokens - 1) over the tile's deferred pre-tokens (atomic adds)
     uint64_t* tile_base;    // [n_tiles + 1] exclusive scan of the tile token totals
     uint32_t* tile_doc0;    // [n_tiles + 1] first document whose start is >= the tile start
     uint32_t* doc_item;     // [n_docs + 1] stream index (inside its tile) of the document's first item
     SlowEntry* slow;        // [slow_cap]
+    SlowEntry* miss;        // [miss_cap]
     int32_t* pool;          // [pool_cap] tokens of slow pre-tokens
     uint8_t* scratch;       // [scratch_cap] symbol arrays of pre-tokens too long for LDS
     Status* status;
-    uint64_t slow_cap, pool_cap, scratch_cap;
+    uint64_t slow_cap, miss_cap, pool_cap, scratch_cap;
 };
 
 struct EncodeArgs {
@@ -83,7 +86,7 @@ struct EncodeArgs {
 
 inline uint64_t num_tiles(uint64_t n_bytes) { return n_bytes == 0 ? 1 : (n_bytes + kTile - 1) / kTile; }
 
-enum { kEvStart = 0, kEvDocs, kEvTile, kEvSlow, kEvScan, kEvEmit, kEvCount };
+enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvEmit, kEvCount };
 
 // Enqueue the encode pipeline on `stream`; nothing is synchronised.  `ev` (optional, kEvCount
 // events) are recorded between the kernels.  `emit_only` re-runs just the final scatter (after

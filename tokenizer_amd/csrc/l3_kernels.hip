@@ -255,15 +255,242 @@ __global__ void docs_kernel(Workspace W, EncodeArgs A, uint64_t n_tiles) {
 }
 
 // ---- the tile kernel ---------------------------------------------------------------------------------
+// Bit-parallel formulation: every property of a byte (rune start, class, contraction letter, ...) is
+// one bit in a 64-bit word per 64 bytes of the region; the start-of-pre-token predicate of
+// SURVEY.md App. B then is a few dozen 64-bit logic operations per 64 bytes, evaluated by one lane per
+// word (one wave per tile), with neighbouring words fetched by wave shuffles.
+constexpr int kWords = kRegion / 64;
+static_assert(kWords * 64 == kRegion && kWords <= 64, "one wave must hold one mask word per lane");
+typedef unsigned long long u64;
+enum { B_RS = 0, B_L, B_N, B_NL, B_SP, B_WS, B_INV, B_APOS, B_STMD, B_R, B_E, B_V, B_LL, B_NX,
+       B_DS, B_SPS, B_SPB, B_SPE, B_ST, B_CONTN, B_COUNT };
+
+struct TileLds {
+    uint8_t b[kRegion + 16];
+    u64 bm[B_COUNT][kWords + 2];
+    int32_t res[kTile];        // stream item of every own pre-token
+    uint16_t list[kTile];      // compacted own pre-token starts (region-local offsets)
+    uint16_t wpre[kWords + 1]; // own pre-token starts before each mask word
+};
+enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NMISS, TV_NSLOW, TV_MISS0, TV_SLOW0, TV_COUNT = 8 };
+
+struct TileSrc {  // byte source over the tile's LDS image, LOCAL coordinates [0, n)
+    const TileLds* R;
+    int n;
+    bool hard;
+    __device__ uint32_t b(int64_t q) const { return R->b[q]; }
+    __device__ bool ds(int64_t q) const { return (q == n && hard) || ((R->bm[B_DS][q >> 6] >> (q & 63)) & 1ull); }
+    __device__ int64_t lo() const { return 0; }
+    __device__ int64_t hi() const { return n; }
+};
+
+__device__ __forceinline__ int find_next_bit64(const u64* bits, int from, int limit) {
+    if (from >= limit) return -1;
+    int w = from >> 6;
+    u64 x = bits[w] & (~0ull << (from & 63));
+    const int wl = (limit - 1) >> 6;
+    for (;;) {
+        if (x) {
+            int q = (w << 6) + __builtin_ctzll(x);
+            return q < limit ? q : -1;
+        }
+        if (++w > wl) return -1;
+        x = bits[w];
+    }
+}
+__device__ __forceinline__ bool any_bit_in(const u64* bits, int from, int to) {  // [from, to), from < to
+    int w0 = from >> 6, w1 = (to - 1) >> 6;
+    u64 m0 = ~0ull << (from & 63), m1 = ~0ull >> (63 - ((to - 1) & 63));
+    if (w0 == w1) return (bits[w0] & m0 & m1) != 0;
+    if (bits[w0] & m0) return true;
+    for (int w = w0 + 1; w < w1; w++)
+        if (bits[w]) return true;
+    return (bits[w1] & m1) != 0;
+}
+
+__device__ __forceinline__ uint32_t up32(uint32_t v) {  // value of the previous lane (lane 0: 0)
+    uint32_t r = __shfl_up(v, 1, 64);
+    return lane_id() == 0 ? 0u : r;
+}
+__device__ __forceinline__ uint32_t dn32(uint32_t v) {  // value of the next lane (lane 63: 0)
+    uint32_t r = __shfl_down(v, 1, 64);
+    return lane_id() == 63 ? 0u : r;
+}
+__device__ __forceinline__ Seg wave_seg_escan(Seg v) {
+    Seg inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Seg t;
+        t.cnt = __shfl_up(inc.cnt, d, 64);
+        t.open = __shfl_up(inc.open, d, 64);
+        if (lane_id() >= d) inc = seg_comb(t, inc);
+    }
+    Seg ex;
+    ex.cnt = __shfl_up(inc.cnt, 1, 64);
+    ex.open = __shfl_up(inc.open, 1, 64);
+    if (lane_id() == 0) { ex.cnt = 0; ex.open = 1; }
+    return ex;
+}
+
+// Start-of-pre-token bits of the whole region, by the lanes of ONE wave (lane w = mask word w).
+// `edge_digits`: number of Nd runes immediately before the tile start when a digit run fills the
+// whole look-behind halo (only read when `use_edge`).  Writes bm[B_ST], bm[B_N], bm[B_CONTN], wpre[];
+// returns flags: bit0 a digit run reaches the region start (edge count needed), bit1 multi-byte digits.
+__device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_hi, int eval_hi, bool region_at_text_start,
+                                                bool use_edge, uint32_t edge_digits, int* n_pre_out) {
+    const int w = lane_id();
+    const bool act = w < kWords;
+#define L3_LD(prop) (act ? R.bm[prop][w] : 0ull)
+    const u64 SPB = L3_LD(B_SPB), nspb = ~SPB;
+    const u64 RS = L3_LD(B_RS) & nspb;
+    const u64 L = L3_LD(B_L) & nspb, N = L3_LD(B_N) & nspb, NL = L3_LD(B_NL) & nspb, SP = L3_LD(B_SP) & nspb,
+              WS = L3_LD(B_WS) & nspb;
+    const u64 P = RS & ~(L | N | NL | SP | WS);
+    const u64 SEG = L3_LD(B_DS) | L3_LD(B_SPE);
+    const u64 APOS = L3_LD(B_APOS) & nspb, STMD = L3_LD(B_STMD) & nspb, cR = L3_LD(B_R) & nspb, cE = L3_LD(B_E) & nspb,
+              cV = L3_LD(B_V) & nspb, cLL = L3_LD(B_LL) & nspb;
+    const u64 NX = L3_LD(B_NX) & nspb;
+    const u64 cont = ~RS;
+    // class of the rune that CONTAINS each byte (classes smeared over continuation bytes)
+    u64 sL = L, sN = N, sWS = WS, sP = P;
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        uint32_t t = (uint32_t)(sL >> 63) | ((uint32_t)(sN >> 63) << 1) | ((uint32_t)(sWS >> 63) << 2) | ((uint32_t)(sP >> 63) << 3);
+        uint32_t u = up32(t);
+        sL |= ((sL << 1) | (u & 1u)) & cont;
+        sN |= ((sN << 1) | ((u >> 1) & 1u)) & cont;
+        sWS |= ((sWS << 1) | ((u >> 2) & 1u)) & cont;
+        sP |= ((sP << 1) | ((u >> 3) & 1u)) & cont;
+    }
+    // class of the previous rune, at every rune start
+    u64 p_L, p_N, p_NL, p_SP, p_WS, p_P;
+    {
+        uint32_t t = (uint32_t)(sL >> 63) | ((uint32_t)(sN >> 63) << 1) | ((uint32_t)(NL >> 63) << 2) | ((uint32_t)(SP >> 63) << 3) |
+                     ((uint32_t)(sWS >> 63) << 4) | ((uint32_t)(sP >> 63) << 5);
+        uint32_t u = up32(t);
+        p_L = (sL << 1) | (u & 1u);
+        p_N = (sN << 1) | ((u >> 1) & 1u);
+        p_NL = (NL << 1) | ((u >> 2) & 1u);
+        p_SP = (SP << 1) | ((u >> 3) & 1u);
+        p_WS = (sWS << 1) | ((u >> 4) & 1u);
+        p_P = (sP << 1) | ((u >> 5) & 1u);
+    }
+    // apostrophe that can start a contraction: at a segment start or after L / N / newline / other white space
+    const u64 AS = APOS & (SEG | p_L | p_N | p_NL | p_WS);
+    // punctuation rune preceded (in its segment) by punctuation or ' ': a letter after it starts a token
+    u64 sQ = P & ~SEG & (p_P | p_SP);
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        uint32_t u = up32((uint32_t)(sQ >> 63));
+        sQ |= ((sQ << 1) | (u & 1u)) & cont;
+    }
+    u64 p_Q;
+    u64 AS2, AS3, STMD1, SEG1, SEG2, R2, E1, V2, LL1, LL2;
+    {
+        // top three bits of the previous word of every mask that is shifted by up to 3
+        uint32_t t = (uint32_t)(AS >> 61) | ((uint32_t)(SEG >> 61) << 3) | ((uint32_t)(cR >> 61) << 6) | ((uint32_t)(cV >> 61) << 9) |
+                     ((uint32_t)(cLL >> 61) << 12) | ((uint32_t)(STMD >> 61) << 15) | ((uint32_t)(cE >> 61) << 18) |
+                     ((uint32_t)(sQ >> 61) << 21);
+        uint32_t u = up32(t);
+#define L3_SHL(X, k, f) (((X) << (k)) | (u64)((((u) >> (f)) & 7u) >> (3 - (k))))
+        AS2 = L3_SHL(AS, 2, 0); AS3 = L3_SHL(AS, 3, 0);
+        SEG1 = L3_SHL(SEG, 1, 3); SEG2 = L3_SHL(SEG, 2, 3);
+        R2 = L3_SHL(cR, 2, 6); V2 = L3_SHL(cV, 2, 9);
+        LL1 = L3_SHL(cLL, 1, 12); LL2 = L3_SHL(cLL, 2, 12);
+        STMD1 = L3_SHL(STMD, 1, 15); E1 = L3_SHL(cE, 1, 18);
+        p_Q = L3_SHL(sQ, 1, 21);
+#undef L3_SHL
+    }
+    const u64 ce2 = AS2 & STMD1 & ~SEG1;
+    const u64 ce3 = AS3 & ((R2 & E1) | (V2 & E1) | (LL2 & LL1)) & ~SEG2 & ~SEG1;
+    const u64 startL = L & (p_N | p_NL | p_Q | (p_L & (ce2 | ce3)));
+    const u64 startP = P & (p_L | p_N | p_WS | p_NL);
+    // white space: the look-ahead "followed by a non-space rune of the same segment"
+    const u64 Wany = NL | SP | WS;
+    u64 B;
+    {
+        const u64 NWS = RS & ~SEG & ~Wany;
+        B = (NWS >> 1) | ((u64)(dn32((uint32_t)NWS) & 1u) << 63);
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            u64 x = B & cont;
+            B |= (x >> 1) | ((u64)(dn32((uint32_t)x) & 1u) << 63);
+        }
+    }
+    const u64 pws = p_NL | p_SP | p_WS;
+    const u64 startW = Wany & (p_L | p_N | (p_P & ~NL) | (pws & ~NL & (p_NL | B)));
+    // digits: groups of three inside every run of Nd runes
+    const u64 contN = N & p_N & ~SEG;
+    const bool mb = __ballot(NX != 0) != 0;
+    uint32_t flags = mb ? 2u : 0u;
+    u64 DST = 0;
+    if (!mb) {
+        u64 c2 = contN;
+        if (w == 0 && !region_at_text_start && !(SEG & 1ull)) c2 |= N & 1ull;  // unknown: assume linked
+        Seg sg;
+        if (!(N >> 63)) { sg.cnt = 0; sg.open = 0; }
+        else {
+            u64 t = ~c2;
+            if (t == 0) { sg.cnt = 64; sg.open = 1; }
+            else { sg.cnt = (uint32_t)__builtin_clzll(t) + 1u; sg.open = 0; }
+        }
+        Seg c = wave_seg_escan(sg);
+        const bool linked0 = (contN & 1ull) != 0;
+        const bool from_edge = linked0 && c.open && w >= 1 && !region_at_text_start;
+        if (__ballot(from_edge) != 0) flags |= 1u;
+        uint32_t carry = linked0 ? c.cnt : 0u;
+        if (from_edge && use_edge) carry = edge_digits + 64u * (uint32_t)(w - 1);  // own_lo is bit 0 of word 1
+        u64 rem = N;
+        while (rem) {
+            const int s = __builtin_ctzll(rem);
+            const int extra = s == 63 ? 0 : __builtin_ctzll(~(contN >> (s + 1)));
+            const int len = 1 + (extra > 63 - s ? 63 - s : extra);
+            const uint32_t o = (s == 0 && linked0) ? carry % 3u : 0u;
+            const int first = s + (int)((3u - o) % 3u);
+            const u64 runmask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << s;
+            if (first < 64) DST |= (0x9249249249249249ull << first) & runmask;
+            rem &= ~runmask;
+        }
+    }
+    const u64 startN = N & (~p_N | DST);
+    u64 ST = RS & (SEG | startL | startP | startW | startN);
+    // keep only decidable positions
+    {
+        const int lo = w * 64;
+        if (eval_hi <= lo) ST = 0;
+        else if (eval_hi < lo + 64) ST &= (1ull << (eval_hi - lo)) - 1ull;
+    }
+    if (act) {
+        R.bm[B_ST][w] = ST;
+        R.bm[B_N][w] = N;
+        R.bm[B_CONTN][w] = contN;
+    }
+    // own starts before every word
+    u64 own = ST;
+    {
+        const int lo = w * 64;
+        if (own_lo >= lo + 64 || own_hi <= lo) own = 0;
+        else {
+            if (own_lo > lo) own &= ~0ull << (own_lo - lo);
+            if (own_hi < lo + 64) own &= (1ull << (own_hi - lo)) - 1ull;
+        }
+    }
+    uint32_t cnt = (uint32_t)__popcll(own);
+    uint32_t inc = wave_iscan(cnt);
+    if (act) R.wpre[w] = (uint16_t)(inc - cnt);
+    uint32_t total = __shfl(inc, 63, 64);
+    *n_pre_out = (int)total;
+#undef L3_LD
+    return flags;
+}
+
 __global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace W, EncodeArgs A) {
-    __shared__ __align__(16) RegionLds R;
-    __shared__ uint32_t tmp[16];
+    __shared__ __align__(16) TileLds R;
     __shared__ unsigned long long tmp64[8];
-    __shared__ Seg segtmp[4];
-    __shared__ int vars[V_COUNT];
+    __shared__ int vars[TV_COUNT];
 
     if (W.status->flags & kBadOffsets) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const uint64_t tile = blockIdx.x;
     const uint64_t t_lo = tile * (uint64_t)kTile;
     const uint64_t t_hi = t_lo + kTile < A.n_bytes ? t_lo + kTile : A.n_bytes;
@@ -273,266 +500,255 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace 
     const int own_lo = (int)(t_lo - g_lo), own_hi = (int)(t_hi - g_lo);
     const bool hard = g_hi == A.n_bytes;
     const int eval_hi = hard ? n : n - kEvalSlack;
-    const int c0 = tid * kPer;
     const uint32_t d0 = W.tile_doc0[tile];
 
-    // -- stage bytes, document-start bits
-    for (int i = tid; i < kBitWords; i += kTileThreads) { R.dsb[i] = 0; R.stb[i] = 0; }
-    region_load(R, A.text, g_lo, n);
+    // -- stage bytes, clear what is accumulated with atomics
+    for (int i = tid; i < kWords + 2; i += kTileThreads) {
+        R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0;
+    }
+    if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; }
+    {
+        const uint8_t* srcp = A.text + g_lo;
+        const bool aligned = (((uintptr_t)srcp) & 15u) == 0;
+        for (int g = tid; g * 16 < n + 16; g += kTileThreads) {
+            int o = g * 16;
+            if (aligned && o + 16 <= n) {
+                *reinterpret_cast<uint4*>(&R.b[o]) = *reinterpret_cast<const uint4*>(srcp + o);
+            } else {
+                for (int k = 0; k < 16; k++)
+                    if (o + k < kRegion + 16) R.b[o + k] = (o + k < n) ? srcp[o + k] : (uint8_t)0;
+            }
+        }
+    }
     __syncthreads();
     if (tid == 0 && d0 > 0) {
         uint64_t pos = A.doc_off[d0 - 1];
-        if (pos >= g_lo) atomicOr(&R.dsb[(pos - g_lo) >> 5], 1u << ((pos - g_lo) & 31));
+        if (pos >= g_lo) atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
     }
     for (uint64_t d = (uint64_t)d0 + tid; d <= A.n_docs; d += kTileThreads) {
         uint64_t pos = A.doc_off[d];
         if (pos >= g_hi) break;
-        atomicOr(&R.dsb[(pos - g_lo) >> 5], 1u << ((pos - g_lo) & 31));
+        atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
     }
     __syncthreads();
 
-    LdsSrc src{&R, n, hard};
-    region_classify(R, src, T);
-
-    // -- offset of every Nd rune inside its digit run, mod 3 (state_machine.go:178-191: groups of <= 3)
-    {
-        Seg sg; sg.cnt = 0; sg.open = 1;
-        int first_break = kRegion + 1;
+    // -- per-byte properties as ballots (state_machine.go:36,310-320), special-token literals (special.go:12)
+    const TileSrc src{&R, n, hard};
 #pragma unroll 1
-        for (int j = 0; j < kPer; j++) {
-            int q = c0 + j;
-            if (q >= n) break;
-            uint32_t w = R.a[q];
-            if (!(w & I_RUNE)) continue;
-            bool isn = (w & I_CLS) == C_N;
-            if ((w & I_SEG) || !isn) {
-                sg.cnt = 0; sg.open = 0;
-                if (first_break > kRegion) first_break = q;
-            }
-            if (isn) { R.a[q] = w | ((sg.cnt % 3u) << I_DOFF_SHIFT); sg.cnt++; }
+    for (int g = wave; g < kWords; g += kTileThreads / 64) {
+        const int q = g * 64 + lane;
+        const uint32_t b = q < n ? (uint32_t)R.b[q] : 0x100u;
+        bool rs = false, cl = false, cn = false, cnl = false, csp = false, cws = false, inv = false, nx = false;
+        const uint32_t lo = b | 0x20u;
+        if (b < 0x80u) {
+            rs = true;
+            cl = (lo - 'a') < 26u;
+            cn = (b - '0') < 10u;
+            csp = b == ' ';
+            cnl = b == '\n' || b == '\r';
+            cws = (b - 9u) < 5u && !cnl;
+        } else if (b < 0x100u) {
+            const uint32_t wd = byte_info(src, q, T.cls_stage1, T.cls_blocks);
+            const uint32_t c = wd & I_CLS;
+            rs = (wd & I_RUNE) != 0;
+            cl = rs && c == C_L;
+            cn = rs && c == C_N;
+            nx = cn;
+            cws = rs && c == C_WS;
+            inv = (wd & I_INVALID) != 0;
         }
-        Seg carry = block_seg_escan(sg, segtmp);
-        if (carry.cnt % 3u) {
-#pragma unroll 1
-            for (int j = 0; j < kPer; j++) {
-                int q = c0 + j;
-                if (q >= n || q >= first_break) break;
-                uint32_t w = R.a[q];
-                if (!(w & I_RUNE) || (w & I_CLS) != C_N) continue;
-                uint32_t off = (((w >> I_DOFF_SHIFT) & 3u) + carry.cnt) % 3u;
-                R.a[q] = (w & ~(3u << I_DOFF_SHIFT)) | (off << I_DOFF_SHIFT);
+        const u64 m_rs = __ballot(rs), m_l = __ballot(cl), m_n = __ballot(cn), m_nl = __ballot(cnl), m_sp = __ballot(csp),
+                  m_ws = __ballot(cws), m_inv = __ballot(inv), m_nx = __ballot(nx), m_apos = __ballot(b == '\''),
+                  m_stmd = __ballot(lo == 's' || lo == 't' || lo == 'm' || lo == 'd'), m_r = __ballot(lo == 'r'),
+                  m_e = __ballot(lo == 'e'), m_v = __ballot(lo == 'v'), m_ll = __ballot(lo == 'l');
+        if (lane == 0) {
+            R.bm[B_RS][g] = m_rs; R.bm[B_L][g] = m_l; R.bm[B_N][g] = m_n; R.bm[B_NL][g] = m_nl; R.bm[B_SP][g] = m_sp;
+            R.bm[B_WS][g] = m_ws; R.bm[B_INV][g] = m_inv; R.bm[B_NX][g] = m_nx; R.bm[B_APOS][g] = m_apos;
+            R.bm[B_STMD][g] = m_stmd; R.bm[B_R][g] = m_r; R.bm[B_E][g] = m_e; R.bm[B_V][g] = m_v; R.bm[B_LL][g] = m_ll;
+        }
+        if (b == '<') {
+            int canon = 0;
+            const int len = special_match(src, q, &canon);
+            if (len) {
+                atomicOr(&R.bm[B_SPE][q >> 6], 1ull << (q & 63));
+                atomicOr(&R.bm[B_SPE][(q + len) >> 6], 1ull << ((q + len) & 63));
+                if (T.special_id[canon] != 0) {  // tokenizer.go:236: only a piece whose lookup is non-zero is special
+                    atomicOr(&R.bm[B_SPS][q >> 6], 1ull << (q & 63));
+                    for (int k = 1; k < len; k++) atomicOr(&R.bm[B_SPB][(q + k) >> 6], 1ull << ((q + k) & 63));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // -- start-of-pre-token bits (one wave), digit runs that need more context than the halo holds
+    if (wave == 0) {
+        int n_pre = 0;
+        uint32_t fl = compute_starts(R, own_lo, own_hi, eval_hi, g_lo == 0, false, 0u, &n_pre);
+        if (lane == 0) {
+            vars[TV_NPRE] = n_pre;
+            vars[TV_MB] = (fl & 2u) ? 1 : 0;
+            vars[TV_NEED] = ((fl & 1u) || ((fl & 2u) && g_lo > 0)) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (vars[TV_NEED] || vars[TV_MB]) {  // rare: long digit runs / digits outside ASCII
+        uint32_t edge = 0;
+        const bool need = vars[TV_NEED] != 0, mbd = vars[TV_MB] != 0;
+        if (need) {
+            // runes right before the tile start, inside the document that contains it
+            const bool at_doc_start = (R.bm[B_DS][own_lo >> 6] >> (own_lo & 63)) & 1ull;
+            if (!at_doc_start) {
+                int64_t seg_lo = (int64_t)A.doc_off[d0 - 1], seg_hi = (int64_t)A.doc_off[d0];
+                edge = digits_before_global(A.text, seg_lo, seg_hi, (int64_t)t_lo, T, tmp64);
             }
         }
         __syncthreads();
-        // a digit run that fills the whole look-behind halo: count it in global memory
-        if (tid == 0) {
-            int need = 0;
-            if (g_lo > 0 && own_lo < n) {
-                uint32_t w = R.a[own_lo];
-                if ((w & I_RUNE) && (w & I_CLS) == C_N && !(w & I_SEG)) {
-                    need = 1;
-                    for (int q = own_lo - 1; q >= 8; q--) {
-                        uint32_t w2 = R.a[q];
-                        if (w2 & I_SPBODY) { need = 0; break; }
-                        if (!(w2 & I_RUNE)) continue;
-                        if ((w2 & I_CLS) != C_N || (w2 & I_SEG)) { need = 0; break; }
+        if (!mbd) {
+            if (wave == 0) {
+                int n_pre = 0;
+                compute_starts(R, own_lo, own_hi, eval_hi, g_lo == 0, true, edge, &n_pre);
+                if (lane == 0) vars[TV_NPRE] = n_pre;
+            }
+        } else if (tid == 0) {
+            // serial walk over the Nd rune starts; the other start bits are already final
+            uint32_t off = 0;
+            bool first_own = need;
+            int total = 0;
+            for (int w = 0; w < kWords; w++) {
+                u64 nn = R.bm[B_N][w];
+                const u64 cnn = R.bm[B_CONTN][w];
+                u64 st = R.bm[B_ST][w] & ~(nn & cnn);   // linked digits: decided here
+                while (nn) {
+                    const int bpos = __builtin_ctzll(nn);
+                    nn &= nn - 1;
+                    const int q = w * 64 + bpos;
+                    if ((cnn >> bpos) & 1ull) {
+                        if (first_own && q >= own_lo) off = edge; else off++;
+                        if (off % 3u == 0u && q < eval_hi) st |= 1ull << bpos;
+                    } else {
+                        off = 0;
                     }
+                    if (q >= own_lo) first_own = false;
                 }
+                R.bm[B_ST][w] = st;
+                u64 own = st;
+                const int lo = w * 64;
+                if (own_lo >= lo + 64 || own_hi <= lo) own = 0;
+                else {
+                    if (own_lo > lo) own &= ~0ull << (own_lo - lo);
+                    if (own_hi < lo + 64) own &= (1ull << (own_hi - lo)) - 1ull;
+                }
+                R.wpre[w] = (uint16_t)total;
+                total += __popcll(own);
             }
-            vars[V_NEED] = need;
-            vars[V_FB] = n;
+            vars[TV_NPRE] = total;
         }
         __syncthreads();
-        if (vars[V_NEED]) {
-            int64_t seg_lo = (int64_t)A.doc_off[d0 - 1], seg_hi = (int64_t)A.doc_off[d0];
-            uint32_t cnt = digits_before_global(A.text, seg_lo, seg_hi, (int64_t)t_lo, T, tmp64);
-            uint32_t old = (R.a[own_lo] >> I_DOFF_SHIFT) & 3u;
-            uint32_t adj = (cnt % 3u + 3u - old) % 3u;
-            // first break at or after own_lo ends the run
-#pragma unroll 1
-            for (int j = 0; j < kPer; j++) {
-                int q = c0 + j;
-                if (q >= n) break;
-                if (q <= own_lo) continue;
-                uint32_t w = R.a[q];
-                if (w & I_SPBODY) { atomicMin(&vars[V_FB], q); break; }
-                if (!(w & I_RUNE)) continue;
-                if ((w & I_CLS) != C_N || (w & I_SEG)) { atomicMin(&vars[V_FB], q); break; }
-            }
-            __syncthreads();
-            const int fb = vars[V_FB];
-            if (adj) {
-#pragma unroll 1
-                for (int j = 0; j < kPer; j++) {
-                    int q = c0 + j;
-                    if (q < own_lo || q >= fb || q >= n) continue;
-                    uint32_t w = R.a[q];
-                    if (!(w & I_RUNE)) continue;
-                    uint32_t off = (((w >> I_DOFF_SHIFT) & 3u) + adj) % 3u;
-                    R.a[q] = (w & ~(3u << I_DOFF_SHIFT)) | (off << I_DOFF_SHIFT);
-                }
-            }
-            __syncthreads();
-        }
     }
+    const uint32_t n_pre = (uint32_t)vars[TV_NPRE];
+    const u64* ST = R.bm[B_ST];
 
-    // -- start-of-pre-token predicate on every decidable position from the tile start on
-    uint32_t mymask = 0, ownmask = 0;
-#pragma unroll 1
-    for (int j = 0; j < kPer; j++) {
-        int q = c0 + j;
-        if (q < own_lo || q >= eval_hi) continue;
-        uint32_t w = R.a[q];
-        if (!(w & I_RUNE) || (w & I_SPBODY)) continue;
-        if ((A.flags & 0x400u) ? ((w & I_CLS) >= C_SP || (w & I_SEG)) : starts_pretoken(src, q, (int)((w >> I_DOFF_SHIFT) & 3u))) {
-            mymask |= 1u << j;
-            if (q < own_hi) ownmask |= 1u << j;
-        }
-    }
-    if (mymask) {
-        int wd = c0 >> 5, sh = c0 & 31;
-        atomicOr(&R.stb[wd], mymask << sh);
-        if (sh + kPer > 32) atomicOr(&R.stb[wd + 1], mymask >> (32 - sh));
-    }
-    if (A.kinds) {
-        for (int j = 0; j < kPer; j++) {
-            int q = c0 + j;
-            if (q < own_lo || q >= own_hi) continue;
-            A.kinds[g_lo + q] = (ownmask >> j) & 1u ? ((R.a[q] & I_SPECIAL) ? 2 : 1) : 0;
-        }
-    }
-    uint32_t n_pre;
+    // -- compacted list of own pre-token starts (8 byte positions per thread)
     {
-        uint32_t ex = block_escan(__popc(ownmask), tmp, &n_pre);
-        uint32_t m = ownmask;
-        while (m) {
-            int j = __builtin_ctz(m);
-            m &= m - 1;
-            R.list[ex++] = (uint16_t)(c0 + j);
+        const int pos = own_lo + tid * (kTile / kTileThreads);
+        if (pos < own_hi) {
+            const int wd = pos >> 6, sh = pos & 63;
+            const u64 word = ST[wd];
+            u64 ownw = word;
+            if (own_lo > wd * 64) ownw &= ~0ull << (own_lo - wd * 64);
+            uint32_t bits = (uint32_t)(word >> sh) & ((1u << (kTile / kTileThreads)) - 1u);
+            if (own_hi - pos < kTile / kTileThreads) bits &= (1u << (own_hi - pos)) - 1u;
+            uint32_t base = R.wpre[wd] + (uint32_t)__popcll(ownw & ((1ull << sh) - 1ull));
+            if (A.kinds) {
+                const u64 sps = R.bm[B_SPS][wd] >> sh;
+                for (int j = 0; j < kTile / kTileThreads && pos + j < own_hi; j++)
+                    A.kinds[g_lo + pos + j] = (bits >> j) & 1u ? (((sps >> j) & 1ull) ? 2 : 1) : 0;
+            }
+            while (bits) {
+                int j = __builtin_ctz(bits);
+                bits &= bits - 1;
+                R.list[base++] = (uint16_t)(pos + j);
+            }
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        vars[V_FIRST] = n_pre ? R.list[0] : 0;
-        if (!n_pre) vars[V_ELAST] = 0;
-    }
 
-    // -- per pre-token: special id / whole-string vocabulary probe / defer
+    // -- per pre-token: special id / whole-string vocabulary probe (bpe.go:27-33) / defer.  One stream item each.
 #pragma unroll 1
     for (uint32_t k = tid; k < n_pre; k += kTileThreads) {
         const int s = R.list[k];
-        int e = find_next_bit(R.stb, s + 1, eval_hi);
-        if (e < 0 && hard) e = n;
-        const uint32_t w = R.a[s];
-        if (k == n_pre - 1) vars[V_ELAST] = e < 0 ? s + 1 : e;
-        if (e < 0) {  // ends beyond what this tile can see
-            R.a[s] = (uint32_t)kSlowMark; R.p[s] = 0;
-            continue;
-        }
-        const int len = e - s;
-        if (w & I_SPECIAL) {
-            R.a[s] = R.p[s];
-            for (int q = s + 1; q < e; q++) R.a[q] = (uint32_t)kDead;
-            continue;
-        }
-        uint32_t inval = 0;
-        for (int q = s; q < e; q++) inval |= R.a[q] & I_INVALID;
-        int32_t id = -1;
-        if (A.flags & 0x200u) id = 1;
-        else if (!inval && len <= kMaxTokenBytes) id = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)R.b[s + i]; }, (uint32_t)len);
-        if (id >= 0) {
-            R.a[s] = (uint32_t)id;
-            for (int q = s + 1; q < e; q++) R.a[q] = (uint32_t)kDead;
-        } else if (!inval && len <= kLaneMax) {
-            R.a[s] = (uint32_t)kMissMark; R.p[s] = (uint32_t)len;
+        int32_t item;
+        if ((R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull) {
+            int canon = 0;
+            special_match(src, s, &canon);
+            item = T.special_id[canon];
         } else {
-            R.a[s] = (uint32_t)kSlowMark; R.p[s] = (uint32_t)len;
-            for (int q = s + 1; q < e; q++) R.a[q] = (uint32_t)kDead;
-        }
-    }
-    __syncthreads();
-    const int first = vars[V_FIRST], e_last = vars[V_ELAST];
-
-    // -- gather the pre-tokens that need merging, then merge each in place (one lane per pre-token)
-    uint32_t n_miss;
-    {
-        uint32_t cnt = 0;
-        for (int j = 0; j < kPer; j++) {
-            int q = c0 + j;
-            if (q >= first && q < e_last && (int32_t)R.a[q] == kMissMark) cnt++;
-        }
-        uint32_t ex = block_escan(cnt, tmp, &n_miss);
-        if (cnt) {
-            for (int j = 0; j < kPer; j++) {
-                int q = c0 + j;
-                if (q >= first && q < e_last && (int32_t)R.a[q] == kMissMark) R.list[ex++] = (uint16_t)q;
-            }
-        }
-    }
-    __syncthreads();
-    {
-        int32_t* sym = reinterpret_cast<int32_t*>(R.a);
-        uint32_t* pr = R.p;
-#pragma unroll 1
-        for (uint32_t k = tid; k < n_miss; k += kTileThreads) {
-            const int s = R.list[k];
-            const int e = s + (int)R.p[s];
-            for (int q = s; q < e; q++) {
-                uint32_t b0 = R.b[q];
-                sym[q] = T.byte_tok[b0];
-                pr[q] = (q + 1 < e) ? T.bytepair[(b0 << 8) | R.b[q + 1]] : kNoPrio;
-            }
-            if (!(A.flags & 0x100u)) merge_span(T, sym, pr, s, e);
-        }
-    }
-    __syncthreads();
-
-    // -- compact the surviving ids (and slow placeholders) into the tile's stream
-    uint32_t cnt = 0;  // low 16: items, high 16: slow placeholders
-    for (int j = 0; j < kPer; j++) {
-        int q = c0 + j;
-        if (q < first || q >= e_last) continue;
-        int32_t v = (int32_t)R.a[q];
-        if (v >= 0) cnt += 1u;
-        else if (v == kSlowMark) cnt += 0x10001u;
-    }
-    uint32_t tot;
-    uint32_t ex = block_escan(cnt, tmp, &tot);
-    const uint32_t n_items = tot & 0xFFFFu, n_slow = tot >> 16;
-    if (tid == 0) {
-        uint32_t s0 = n_slow ? atomicAdd(&W.status->slow_count, n_slow) : 0u;
-        vars[V_SLOW0] = (int)s0;
-        W.tile_items[tile] = n_items;
-        W.tile_nslow[tile] = n_slow;
-        W.tile_slow0[tile] = s0;
-        if (n_slow && (uint64_t)s0 + n_slow > W.slow_cap) atomicOr(&W.status->flags, kOvfSlow);
-    }
-    // chunk prefixes for the per-document item index (list[] is free now)
-    R.list[tid] = (uint16_t)(ex & 0xFFFFu);
-    __syncthreads();
-    {
-        const uint32_t slow0 = (uint32_t)vars[V_SLOW0];
-        int32_t* out = W.stream + tile * (uint64_t)kTileCap;
-        uint32_t ii = ex & 0xFFFFu, si = ex >> 16;
-        for (int j = 0; j < kPer; j++) {
-            int q = c0 + j;
-            if (q < first || q >= e_last) continue;
-            int32_t v = (int32_t)R.a[q];
-            if (v >= 0) {
-                out[ii++] = v;
-            } else if (v == kSlowMark) {
-                out[ii++] = kSlowMark;
-                uint64_t ei = (uint64_t)slow0 + si++;
-                if (ei < W.slow_cap) {
-                    SlowEntry se;
-                    se.start = g_lo + (uint64_t)q;
-                    se.scan_from = g_lo + (uint64_t)eval_hi;
-                    se.len = R.p[q];
-                    se.tile = (uint32_t)tile;
-                    se.count = 0; se.pad = 0; se.pool_off = 0;
-                    W.slow[ei] = se;
+            int e = find_next_bit64(ST, s + 1, eval_hi);
+            if (e < 0 && hard) e = n;
+            int32_t id = -1;
+            bool inval = false;
+            const int len = e - s;
+            if (e >= 0) {
+                inval = any_bit_in(R.bm[B_INV], s, e);
+                if (A.flags & 0x200u) id = 1;
+                else if (!inval && len <= kVocabInline) {
+                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
+                    const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
+                    const uint32_t sh = (uint32_t)(s & 3) * 8u;
+                    uint32_t w0 = __funnelshift_r(x0, x1, sh), w1 = __funnelshift_r(x1, x2, sh), w2 = __funnelshift_r(x2, x3, sh);
+                    if (len < 4) { w0 &= (1u << (len * 8)) - 1u; w1 = 0; w2 = 0; }
+                    else if (len < 8) { w1 = len == 4 ? 0u : (w1 & ((1u << ((len - 4) * 8)) - 1u)); w2 = 0; }
+                    else if (len < 12) { w2 = len == 8 ? 0u : (w2 & ((1u << ((len - 8) * 8)) - 1u)); }
+                    id = vocab_lookup_short(T, w0, w1, w2, (uint32_t)len);
+                } else if (!inval && len <= kMaxTokenBytes) {
+                    id = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)R.b[s + i]; }, (uint32_t)len);
                 }
             }
+            if (id >= 0) item = id;
+            else if (e >= 0 && !inval && len <= kLaneMax) item = -2 - (int32_t)atomicAdd(&vars[TV_NMISS], 1);  // local ordinal
+            else item = -2 - (int32_t)(kSlowBase + (uint32_t)atomicAdd(&vars[TV_NSLOW], 1));
+        }
+        R.res[k] = item;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t nm = (uint32_t)vars[TV_NMISS], ns = (uint32_t)vars[TV_NSLOW];
+        uint32_t m0 = nm ? atomicAdd(&W.status->miss_count, nm) : 0u;
+        uint32_t s0 = ns ? atomicAdd(&W.status->slow_count, ns) : 0u;
+        if (nm && (uint64_t)m0 + nm > W.miss_cap) atomicOr(&W.status->flags, kOvfMiss);
+        if (ns && (uint64_t)s0 + ns > W.slow_cap) atomicOr(&W.status->flags, kOvfSlow);
+        vars[TV_MISS0] = (int)m0;
+        vars[TV_SLOW0] = (int)s0;
+        W.tile_items[tile] = n_pre;
+    }
+    __syncthreads();
+    {
+        const uint32_t m0 = (uint32_t)vars[TV_MISS0], s0 = (uint32_t)vars[TV_SLOW0];
+        int32_t* out = W.stream + tile * (uint64_t)kTileCap;
+#pragma unroll 1
+        for (uint32_t k = tid; k < n_pre; k += kTileThreads) {
+            int32_t item = R.res[k];
+            if (item < -1) {  // deferred: global entry index, entry record
+                uint32_t ord = (uint32_t)(-2 - item);
+                const bool slow = ord >= kSlowBase;
+                if (slow) ord -= kSlowBase;
+                const uint64_t ei = (uint64_t)(slow ? s0 : m0) + ord;
+                const int s = R.list[k];
+                int e = find_next_bit64(ST, s + 1, eval_hi);
+                if (e < 0 && hard) e = n;
+                if (ei < (slow ? W.slow_cap : W.miss_cap)) {
+                    SlowEntry se;
+                    se.start = g_lo + (uint64_t)s;
+                    se.scan_from = g_lo + (uint64_t)eval_hi;
+                    se.len = e < 0 ? 0u : (uint32_t)(e - s);
+                    se.tile = (uint32_t)tile;
+                    se.count = 0; se.pad = 0; se.pool_off = 0;
+                    (slow ? W.slow : W.miss)[ei] = se;
+                }
+                item = -2 - (int32_t)((slow ? kSlowBase : 0u) + (uint32_t)ei);
+            }
+            out[k] = item;
         }
     }
     // -- stream index of the first item of every document that starts in this tile
@@ -540,21 +756,98 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace 
         const bool last_tile = tile + 1 == gridDim.x;
         const uint64_t d_end = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
         for (uint64_t d = (uint64_t)d0 + tid; d < d_end; d += kTileThreads) {
-            int pos = (int)(A.doc_off[d] - g_lo);
+            const int pos = (int)(A.doc_off[d] - g_lo);
             uint32_t item;
-            if (pos <= first) item = 0;
-            else if (pos >= e_last) item = n_items;
+            if (pos >= own_hi) item = n_pre;
             else {
-                int ch = pos / kPer;
-                item = R.list[ch];
-                for (int q = ch * kPer; q < pos; q++) {
-                    if (q < first) continue;
-                    int32_t v = (int32_t)R.a[q];
-                    if (v >= 0 || v == kSlowMark) item++;
-                }
+                const int wd = pos >> 6, sh = pos & 63;
+                u64 ownw = ST[wd];
+                if (own_lo > wd * 64) ownw &= ~0ull << (own_lo - wd * 64);
+                item = R.wpre[wd] + (uint32_t)__popcll(ownw & ((1ull << sh) - 1ull));
             }
             W.doc_item[d] = item;
         }
+    }
+}
+
+// ---- the merge kernel: short deferred pre-tokens, one lane each -------------------------------------------
+// Every lane runs the greedy merge loop (bpe.go:36-71) of one pre-token of <= kLaneMax bytes on its own span
+// of a shared LDS symbol array (spans laid out by a prefix sum of the lengths), so all 64 lanes of a wave
+// keep independent probe chains in flight.
+constexpr int kMergeThreads = 256;
+constexpr int kMergeSyms = 4096;
+__global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspace W, EncodeArgs A) {
+    __shared__ int32_t sym[kMergeSyms];
+    __shared__ uint32_t pr[kMergeSyms];
+    __shared__ uint8_t byte_tok[256];
+    __shared__ uint32_t tmp[16];
+    __shared__ unsigned long long tmp64[8];
+    __shared__ unsigned long long pool_base;
+    if (W.status->flags & kBadOffsets) return;
+    const int tid = threadIdx.x;
+    byte_tok[tid] = T.byte_tok[tid];
+    uint64_t n_ent = W.status->miss_count;
+    if (n_ent > W.miss_cap) n_ent = W.miss_cap;
+    __syncthreads();
+#pragma unroll 1
+    for (uint64_t chunk = (uint64_t)blockIdx.x * kMergeThreads; chunk < n_ent; chunk += (uint64_t)gridDim.x * kMergeThreads) {
+        const uint64_t ei = chunk + tid;
+        const bool have = ei < n_ent;
+        uint64_t start = 0;
+        uint32_t len = 0, tile = 0;
+        if (have) { start = W.miss[ei].start; len = W.miss[ei].len; tile = W.miss[ei].tile; }
+        uint32_t total;
+        const uint32_t off = block_escan(len, tmp, &total);
+        bool done = !have || len == 0;
+        uint32_t base = 0, n_out = 0;
+        int32_t toks[4];  // first tokens kept in registers until the pool slot is known; the rest re-read from LDS
+#pragma unroll 1
+        for (;;) {
+            const bool act = !done && off >= base && off + len <= base + (uint32_t)kMergeSyms;
+            int s = 0, e = 0;
+            if (act) {
+                s = (int)(off - base); e = s + (int)len;
+                const uint8_t* src = A.text + start;
+                for (int i = 0; i < (int)len; i += 8) {
+                    uint32_t bb[9];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) bb[j] = (i + j < (int)len) ? (uint32_t)src[i + j] : 0x100u;
+                    uint32_t pp[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) pp[j] = (bb[j + 1] < 0x100u && bb[j] < 0x100u) ? T.bytepair[(bb[j] << 8) | bb[j + 1]] : kNoPrio;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (i + j < (int)len) { sym[s + i + j] = byte_tok[bb[j]]; pr[s + i + j] = pp[j]; }
+                }
+                merge_span(T, sym, pr, s, e);
+                n_out = 0;
+                for (int i = s; i < e; i++) n_out += sym[i] >= 0 ? 1u : 0u;
+            }
+            // pool space for this window's tokens: one atomic per workgroup
+            uint32_t wtot;
+            const uint32_t po = block_escan(act ? n_out : 0u, tmp, &wtot);
+            if (tid == 0) pool_base = wtot ? atomicAdd(&W.status->pool_used, (unsigned long long)wtot) : 0ull;
+            __syncthreads();
+            if (act) {
+                const unsigned long long dst = pool_base + po;
+                if (dst + n_out <= W.pool_cap) {
+                    uint32_t k = 0;
+                    for (int i = s; i < e; i++)
+                        if (sym[i] >= 0) W.pool[dst + k++] = sym[i];
+                } else {
+                    atomicOr(&W.status->flags, kOvfPool);
+                }
+                W.miss[ei].count = n_out;
+                W.miss[ei].pool_off = dst;
+                if (n_out > 1) atomicAdd(&W.tile_extra[tile], n_out - 1);
+                done = true;
+            }
+            const unsigned long long nxt = block_min64(done ? ~0ull : (unsigned long long)off, tmp64);
+            if (nxt == ~0ull) break;
+            base = (uint32_t)nxt;
+        }
+        (void)toks;
+        __syncthreads();
     }
 }
 
@@ -811,7 +1104,7 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
                 lvars[4] = fits ? (long long)off : -1ll;
                 W.slow[ei].count = n_out;
                 W.slow[ei].pool_off = off;
-                atomicAdd(&W.tile_extra[W.slow[ei].tile], n_out);
+                if (n_out > 1) atomicAdd(&W.tile_extra[W.slow[ei].tile], n_out - 1);
             }
             __syncthreads();
             if (lvars[4] >= 0) {
@@ -835,7 +1128,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeA
     for (uint64_t base = 0; base < n_tiles; base += kScanThreads) {
         uint64_t t = base + tid;
         unsigned long long v = 0;
-        if (t < n_tiles) v = (unsigned long long)W.tile_items[t] - W.tile_nslow[t] + W.tile_extra[t];
+        if (t < n_tiles) v = (unsigned long long)W.tile_items[t] + W.tile_extra[t];
         unsigned long long inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -866,23 +1159,26 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeA
 
 // ---- final scatter -------------------------------------------------------------------------------------
 constexpr int kEmitPer = (kTileCap + 1 + kTileThreads - 1) / kTileThreads;  // items per thread
-constexpr int kEmitQueue = 256;
+constexpr int kEmitQueue = 128;
+__device__ __forceinline__ const SlowEntry& deferred_entry(const Workspace& W, int32_t item) {
+    const uint32_t e = (uint32_t)(-2 - item);
+    return e >= kSlowBase ? W.slow[e - kSlowBase] : W.miss[e];
+}
 __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeArgs A) {
     __shared__ uint32_t docinc[kEmitPer * kTileThreads + 1];
     __shared__ uint32_t tokpre[kEmitPer * kTileThreads + 1];
     __shared__ uint32_t tmp[16];
     __shared__ unsigned long long q_out[kEmitQueue];
-    __shared__ uint32_t q_slow[kEmitQueue];
+    __shared__ int32_t q_item[kEmitQueue];
     __shared__ uint32_t q_n;
 
     const uint32_t fl = W.status->flags;
-    if (fl & (kBadOffsets | kOvfSlow | kOvfPool | kOvfScratch)) return;
+    if (fl & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) return;
     if (W.status->total_tokens > A.out_cap) return;
     const int tid = threadIdx.x;
     const uint64_t tile = blockIdx.x;
     const bool last_tile = tile + 1 == gridDim.x;
     const uint32_t n_items = W.tile_items[tile];
-    const uint32_t slow0 = W.tile_slow0[tile];
     const uint64_t d_lo = W.tile_doc0[tile];
     const uint64_t d_hi = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
     const uint32_t bos = A.flags & 1u, eos = (A.flags >> 1) & 1u, be = bos + eos;
@@ -897,29 +1193,22 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
 
     const int c0 = tid * kEmitPer;
     int32_t item[kEmitPer];
-    uint32_t ntok = 0, nsl = 0, ndoc = 0;
+    uint32_t cnts[kEmitPer];
+    uint32_t ntok = 0, ndoc = 0;
 #pragma unroll
     for (int j = 0; j < kEmitPer; j++) {
-        uint32_t i = c0 + j;
+        const uint32_t i = c0 + j;
         item[j] = i < n_items ? in[i] : kDead;
-        if (item[j] == kSlowMark) nsl++;
+        cnts[j] = item[j] >= 0 ? 1u : (item[j] < kDead ? deferred_entry(W, item[j]).count : 0u);
+        ntok += cnts[j];
         if (i <= n_items) ndoc += docinc[i];
     }
-    uint32_t t_sl, t_doc, t_tok;
-    uint32_t sl = block_escan(nsl, tmp, &t_sl);
-    uint32_t cnts[kEmitPer];
-#pragma unroll
-    for (int j = 0; j < kEmitPer; j++) {
-        cnts[j] = item[j] >= 0 ? 1u : 0u;
-        if (item[j] == kSlowMark) cnts[j] = W.slow[slow0 + sl++].count;
-        ntok += cnts[j];
-    }
-    sl -= nsl;
+    uint32_t t_doc, t_tok;
     uint32_t tp = block_escan(ntok, tmp, &t_tok);
     uint32_t dp = block_escan(ndoc, tmp, &t_doc);
 #pragma unroll
     for (int j = 0; j < kEmitPer; j++) {
-        uint32_t i = c0 + j;
+        const uint32_t i = c0 + j;
         if (i > n_items) break;
         dp += docinc[i];  // documents that start at or before item i
         tokpre[i] = tp;
@@ -928,15 +1217,14 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
         const uint64_t o = base + tp + D * be + bos;
         if (item[j] >= 0) {
             A.out_tok[o] = item[j];
-        } else if (item[j] == kSlowMark) {
-            const SlowEntry& se = W.slow[slow0 + sl];
+        } else {
+            const SlowEntry& se = deferred_entry(W, item[j]);
             if (cnts[j] <= 64) {
                 for (uint32_t k = 0; k < cnts[j]; k++) A.out_tok[o + k] = W.pool[se.pool_off + k];
             } else {
                 uint32_t qi = atomicAdd(&q_n, 1u);
-                if (qi < kEmitQueue) { q_out[qi] = o; q_slow[qi] = slow0 + sl; }
+                if (qi < kEmitQueue) { q_out[qi] = o; q_item[qi] = item[j]; }
             }
-            sl++;
         }
         tp += cnts[j];
     }
@@ -948,10 +1236,11 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
         if (bos && d < A.n_docs) A.out_tok[off] = kBosId;
         if (eos && d > 0) A.out_tok[off - 1] = kEosId;
     }
-    // long runs of tokens from the slow pool: copied by the whole workgroup
+    // long runs of tokens from the pool: copied by the whole workgroup (a pre-token with more than 64
+    // tokens has more than 21 bytes, so one tile holds fewer than kEmitQueue of them)
     const uint32_t qn = q_n < kEmitQueue ? q_n : kEmitQueue;
     for (uint32_t qi = 0; qi < qn; qi++) {
-        const SlowEntry& se = W.slow[q_slow[qi]];
+        const SlowEntry& se = deferred_entry(W, q_item[qi]);
         const uint64_t o = q_out[qi];
         for (uint32_t k = tid; k < se.count; k += kTileThreads) A.out_tok[o + k] = W.pool[se.pool_off + k];
     }
@@ -1063,6 +1352,14 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         hipLaunchKernelGGL(tile_kernel, dim3((uint32_t)n_tiles), dim3(kTileThreads), 0, stream, T, W, A);
         L3_LAUNCH_CHECK();
         L3_EV(kEvTile);
+        {
+            uint64_t mgrid = (W.miss_cap + kMergeThreads - 1) / kMergeThreads;
+            if (mgrid > 4096) mgrid = 4096;
+            if (mgrid == 0) mgrid = 1;
+            hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)mgrid), dim3(kMergeThreads), 0, stream, T, W, A);
+            L3_LAUNCH_CHECK();
+        }
+        L3_EV(kEvMerge);
         uint64_t sgrid = W.slow_cap < 2048 ? W.slow_cap : 2048;
         if (sgrid == 0) sgrid = 1;
         hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A);

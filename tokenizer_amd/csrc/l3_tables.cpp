@@ -196,20 +196,21 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
     }
     T.n_merges = (int)rules.size();
 
-    // pair hash table + direct byte-pair table
-    T.pair_log2 = 16;
-    while ((1ull << T.pair_log2) < rules.size() * 3) T.pair_log2++;  // load factor <= 1/3
-    T.pair_slots.assign(1ull << T.pair_log2, kPairEmpty);
+    // pair hash table (two-slot buckets) + direct byte-pair table
+    T.pair_log2 = 15;
+    while ((2ull << T.pair_log2) < rules.size() * 3) T.pair_log2++;  // load factor <= 1/3
+    T.pair_buckets.assign(1ull << T.pair_log2, PairBucket{{kPairEmpty, kPairEmpty}});
     T.bytepair.assign(65536, kNoPrio);
     uint8_t tok_byte[256];  // id -> byte for ids 0..255
     for (int b = 0; b < 256; b++) tok_byte[T.byte_tok[b]] = (uint8_t)b;
-    const uint64_t mask = (1ull << T.pair_log2) - 1;
+    const uint32_t mask = (1u << T.pair_log2) - 1;
     for (const Rule& r : rules) {
         uint32_t prio = (r.merged << 7) | r.sub;
         uint64_t key = pair_key(r.a, r.b);
-        uint64_t s = pair_hash(key, T.pair_log2);
-        while (T.pair_slots[s] != kPairEmpty) s = (s + 1) & mask;
-        T.pair_slots[s] = (key << 24) | prio;
+        uint32_t b = pair_hash(key, T.pair_log2);
+        while (T.pair_buckets[b].s[1] != kPairEmpty) b = (b + 1) & mask;
+        PairBucket& pb = T.pair_buckets[b];
+        pb.s[pb.s[0] == kPairEmpty ? 0 : 1] = (key << 24) | prio;
         if (r.a < 256 && r.b < 256) T.bytepair[((uint32_t)tok_byte[r.a] << 8) | tok_byte[r.b]] = prio;
     }
 
@@ -233,7 +234,8 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
             slot.w[1] = (uint32_t)T.vocab_blob.size();
             T.vocab_blob.insert(T.vocab_blob.end(), s.begin(), s.end());
         }
-        uint32_t p = strhash_slot(h, len, T.vocab_log2);
+        uint32_t p = len <= (uint32_t)kVocabInline ? vocab_hash_short(slot.w[0], slot.w[1], slot.w[2], len, T.vocab_log2)
+                                                   : strhash_slot(h, len, T.vocab_log2);
         while (T.vocab_slots[p].w[3] != kVocabEmpty) p = (p + 1) & vmask;
         T.vocab_slots[p] = slot;
     }
