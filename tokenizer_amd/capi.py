@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "tokenizer_amd", "lib", "libl3hip.so")
+LIB_PATH = os.environ.get("L3HIP_LIB") or os.path.join(ROOT, "tokenizer_amd", "lib", "libl3hip.so")
 DATA_DIR = os.path.join(ROOT, "tokenizer_amd", "data")
 
 L3_OK = 0

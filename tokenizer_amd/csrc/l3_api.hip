@@ -43,9 +43,9 @@ struct l3_ctx {
     HostTables H;
     Tables T{};
     DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes;
-    DevBuf w_stream, w_items, w_extra, w_base, w_doc0, w_docitem, w_slow, w_miss, w_pool, w_scratch, w_status;
+    DevBuf w_stream, w_items, w_extra, w_base, w_doc0, w_docitem, w_slow, w_miss, w_missres, w_pool, w_scratch, w_status;
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
-    uint64_t slow_cap = 0, miss_cap = 0, pool_cap = 0, scratch_cap = 0;
+    uint64_t slow_cap = 0, miss_shard_cap = 0, pool_cap = 0, scratch_cap = 0;
     Status* h_status = nullptr;          // pinned
     unsigned long long* h_total = nullptr;  // pinned
     hipStream_t stream = nullptr;
@@ -113,14 +113,15 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     HIPCHK(c, c->w_doc0.ensure((n_tiles + 1) * 4));
     HIPCHK(c, c->w_docitem.ensure((n_docs + 1) * 4));
     HIPCHK(c, c->w_status.ensure(sizeof(Status)));
-    uint64_t slow_min = n_bytes / 256 + 1024, miss_min = n_bytes / 64 + 1024, pool_min = n_bytes / 8 + 4096,
+    uint64_t slow_min = n_bytes / 256 + 1024, miss_min = n_bytes / 64 / kMissShards + 256, pool_min = n_bytes / 8 + 4096,
              scratch_min = 16ull << 20;
     if (c->slow_cap < slow_min) c->slow_cap = slow_min;
-    if (c->miss_cap < miss_min) c->miss_cap = miss_min;
+    if (c->miss_shard_cap < miss_min) c->miss_shard_cap = miss_min;
     if (c->pool_cap < pool_min) c->pool_cap = pool_min;
     if (c->scratch_cap < scratch_min) c->scratch_cap = scratch_min;
     HIPCHK(c, c->w_slow.ensure(c->slow_cap * sizeof(SlowEntry)));
-    HIPCHK(c, c->w_miss.ensure(c->miss_cap * sizeof(SlowEntry)));
+    HIPCHK(c, c->w_miss.ensure(c->miss_shard_cap * kMissShards * sizeof(MissIn)));
+    HIPCHK(c, c->w_missres.ensure(c->miss_shard_cap * kMissShards * sizeof(uint64_t)));
     HIPCHK(c, c->w_pool.ensure(c->pool_cap * sizeof(int32_t)));
     HIPCHK(c, c->w_scratch.ensure(c->scratch_cap));
     W.stream = c->w_stream.as<int32_t>();
@@ -130,8 +131,9 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     W.tile_doc0 = c->w_doc0.as<uint32_t>();
     W.doc_item = c->w_docitem.as<uint32_t>();
     W.slow = c->w_slow.as<SlowEntry>();
-    W.miss = c->w_miss.as<SlowEntry>();
-    W.miss_cap = c->miss_cap;
+    W.miss_in = c->w_miss.as<MissIn>();
+    W.miss_res = c->w_missres.as<uint64_t>();
+    W.miss_shard_cap = c->miss_shard_cap;
     W.pool = c->w_pool.as<int32_t>();
     W.scratch = c->w_scratch.as<uint8_t>();
     W.status = c->w_status.as<Status>();
@@ -167,7 +169,12 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         }
         bool grow = false;
         if (st.flags & kOvfSlow) { c->slow_cap = (uint64_t)st.slow_count + st.slow_count / 4 + 1024; grow = true; }
-        if (st.flags & kOvfMiss) { c->miss_cap = (uint64_t)st.miss_count + st.miss_count / 4 + 1024; grow = true; }
+        uint64_t miss_total = 0, miss_max = 0;
+        for (int i = 0; i < kMissShards; i++) {
+            miss_total += st.miss_count[i];
+            if (st.miss_count[i] > miss_max) miss_max = st.miss_count[i];
+        }
+        if (st.flags & kOvfMiss) { c->miss_shard_cap = miss_max + miss_max / 4 + 256; grow = true; }
         if (st.flags & kOvfPool) { c->pool_cap = st.pool_used + st.pool_used / 4 + 4096; grow = true; }
         if (st.flags & kOvfScratch) { c->scratch_cap = st.scratch_used + st.scratch_used / 4 + (1ull << 20); grow = true; }
         if (grow) {
@@ -189,7 +196,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         c->counters[1] = st.slow_count;
         c->counters[2] = st.pool_used;
         c->counters[3] = st.scratch_used;
-        c->counters[5] = st.miss_count;
+        c->counters[5] = miss_total;
         *n_tok = st.total_tokens;
         if (W_out) *W_out = W;
         return (st.flags & kOvfOut) ? L3_E_OUTPUT_CAP : L3_OK;
@@ -258,7 +265,7 @@ void l3_destroy(l3_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
-                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_stream, &c->w_items, &c->w_miss,
+                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_stream, &c->w_items, &c->w_miss, &c->w_missres,
                       &c->w_extra, &c->w_base, &c->w_doc0, &c->w_docitem, &c->w_slow, &c->w_pool, &c->w_scratch,
                       &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
                       &c->s_total};

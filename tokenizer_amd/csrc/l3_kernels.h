@@ -20,7 +20,7 @@ constexpr int kSlowThreads = 256;
 constexpr int kSlowLds = 3072;    // symbols of a slow pre-token merged in LDS; longer ones use HBM scratch
 
 // A stream item is a token id (>= 0) or the placeholder -2 - e of a deferred pre-token: e < kSlowBase
-// is an index into Workspace::miss (short: merged one lane each by merge_kernel), e >= kSlowBase is
+// is an index into Workspace::miss_in / miss_res (short: merged one lane each by merge_kernel), e >= kSlowBase is
 // kSlowBase + an index into Workspace::slow (long / invalid UTF-8 / open-ended: slow_kernel).
 constexpr int32_t kDead = -1;
 constexpr uint32_t kSlowBase = 1u << 30;
@@ -49,11 +49,20 @@ enum : uint32_t {
 struct Status {
     uint32_t slow_count;        // entries appended so far (may exceed capacity: overflow)
     uint32_t flags;             // kOvf* / kBadOffsets
-    uint32_t miss_count;        // short entries appended so far (may exceed capacity: overflow)
-    uint32_t pad;
+    uint32_t pad0, pad1;
     unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
     unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the scan)
     unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)
+    // short entries appended so far per shard (may exceed the shard capacity: overflow).  One counter per
+    // shard (shard = tile % kMissShards) keeps ~10^4 tiles from serialising on one atomic word.
+    uint32_t miss_count[64];
+};
+constexpr int kMissShards = 64;
+// a short deferred pre-token (input of merge_kernel); its result is miss_res[i] = pool offset << 8 | tokens
+struct MissIn {
+    uint64_t start;   // global byte offset
+    uint32_t tile;    // owning tile
+    uint32_t len;     // bytes (<= kLaneMax), valid UTF-8
 };
 
 struct Workspace {
@@ -64,11 +73,12 @@ struct Workspace {
     uint32_t* tile_doc0;    // [n_tiles + 1] first document whose start is >= the tile start
     uint32_t* doc_item;     // [n_docs + 1] stream index (inside its tile) of the document's first item
     SlowEntry* slow;        // [slow_cap]
-    SlowEntry* miss;        // [miss_cap]
+    MissIn* miss_in;        // [kMissShards * miss_shard_cap]
+    uint64_t* miss_res;     // [kMissShards * miss_shard_cap]
     int32_t* pool;          // [pool_cap] tokens of slow pre-tokens
     uint8_t* scratch;       // [scratch_cap] symbol arrays of pre-tokens too long for LDS
     Status* status;
-    uint64_t slow_cap, miss_cap, pool_cap, scratch_cap;
+    uint64_t slow_cap, miss_shard_cap, pool_cap, scratch_cap;
 };
 
 struct EncodeArgs {

@@ -484,7 +484,10 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
     return flags;
 }
 
-__global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace W, EncodeArgs A) {
+#ifndef L3_TILE_OCC
+#define L3_TILE_OCC 6
+#endif
+__global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables T, Workspace W, EncodeArgs A) {
     __shared__ __align__(16) TileLds R;
     __shared__ unsigned long long tmp64[8];
     __shared__ int vars[TV_COUNT];
@@ -712,11 +715,12 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace 
         R.res[k] = item;
     }
     __syncthreads();
+    const uint32_t shard = (uint32_t)(tile % kMissShards);
     if (tid == 0) {
         const uint32_t nm = (uint32_t)vars[TV_NMISS], ns = (uint32_t)vars[TV_NSLOW];
-        uint32_t m0 = nm ? atomicAdd(&W.status->miss_count, nm) : 0u;
+        uint32_t m0 = nm ? atomicAdd(&W.status->miss_count[shard], nm) : 0u;
         uint32_t s0 = ns ? atomicAdd(&W.status->slow_count, ns) : 0u;
-        if (nm && (uint64_t)m0 + nm > W.miss_cap) atomicOr(&W.status->flags, kOvfMiss);
+        if (nm && (uint64_t)m0 + nm > W.miss_shard_cap) atomicOr(&W.status->flags, kOvfMiss);
         if (ns && (uint64_t)s0 + ns > W.slow_cap) atomicOr(&W.status->flags, kOvfSlow);
         vars[TV_MISS0] = (int)m0;
         vars[TV_SLOW0] = (int)s0;
@@ -733,20 +737,34 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(Tables T, Workspace 
                 uint32_t ord = (uint32_t)(-2 - item);
                 const bool slow = ord >= kSlowBase;
                 if (slow) ord -= kSlowBase;
-                const uint64_t ei = (uint64_t)(slow ? s0 : m0) + ord;
                 const int s = R.list[k];
                 int e = find_next_bit64(ST, s + 1, eval_hi);
                 if (e < 0 && hard) e = n;
-                if (ei < (slow ? W.slow_cap : W.miss_cap)) {
-                    SlowEntry se;
-                    se.start = g_lo + (uint64_t)s;
-                    se.scan_from = g_lo + (uint64_t)eval_hi;
-                    se.len = e < 0 ? 0u : (uint32_t)(e - s);
-                    se.tile = (uint32_t)tile;
-                    se.count = 0; se.pad = 0; se.pool_off = 0;
-                    (slow ? W.slow : W.miss)[ei] = se;
+                uint64_t ei;
+                if (slow) {
+                    ei = (uint64_t)s0 + ord;
+                    if (ei < W.slow_cap) {
+                        SlowEntry se;
+                        se.start = g_lo + (uint64_t)s;
+                        se.scan_from = g_lo + (uint64_t)eval_hi;
+                        se.len = e < 0 ? 0u : (uint32_t)(e - s);
+                        se.tile = (uint32_t)tile;
+                        se.count = 0; se.pad = 0; se.pool_off = 0;
+                        W.slow[ei] = se;
+                    }
+                    ei += kSlowBase;
+                } else {
+                    const uint64_t li = (uint64_t)m0 + ord;
+                    ei = shard * W.miss_shard_cap + li;
+                    if (li < W.miss_shard_cap) {
+                        MissIn mi;
+                        mi.start = g_lo + (uint64_t)s;
+                        mi.tile = (uint32_t)tile;
+                        mi.len = (uint32_t)(e - s);
+                        W.miss_in[ei] = mi;
+                    }
                 }
-                item = -2 - (int32_t)((slow ? kSlowBase : 0u) + (uint32_t)ei);
+                item = -2 - (int32_t)(uint32_t)ei;
             }
             out[k] = item;
         }
@@ -786,16 +804,18 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
     if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x;
     byte_tok[tid] = T.byte_tok[tid];
-    uint64_t n_ent = W.status->miss_count;
-    if (n_ent > W.miss_cap) n_ent = W.miss_cap;
+    const uint32_t shard = blockIdx.x % kMissShards;
+    uint64_t n_ent = W.status->miss_count[shard];
+    if (n_ent > W.miss_shard_cap) n_ent = W.miss_shard_cap;
+    const uint64_t stride = (uint64_t)(gridDim.x / kMissShards) * kMergeThreads;
     __syncthreads();
 #pragma unroll 1
-    for (uint64_t chunk = (uint64_t)blockIdx.x * kMergeThreads; chunk < n_ent; chunk += (uint64_t)gridDim.x * kMergeThreads) {
-        const uint64_t ei = chunk + tid;
-        const bool have = ei < n_ent;
+    for (uint64_t chunk = (uint64_t)(blockIdx.x / kMissShards) * kMergeThreads; chunk < n_ent; chunk += stride) {
+        const bool have = chunk + tid < n_ent;
+        const uint64_t ei = shard * W.miss_shard_cap + chunk + tid;
         uint64_t start = 0;
         uint32_t len = 0, tile = 0;
-        if (have) { start = W.miss[ei].start; len = W.miss[ei].len; tile = W.miss[ei].tile; }
+        if (have) { const MissIn mi = W.miss_in[ei]; start = mi.start; len = mi.len; tile = mi.tile; }
         uint32_t total;
         const uint32_t off = block_escan(len, tmp, &total);
         bool done = !have || len == 0;
@@ -837,8 +857,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
                 } else {
                     atomicOr(&W.status->flags, kOvfPool);
                 }
-                W.miss[ei].count = n_out;
-                W.miss[ei].pool_off = dst;
+                W.miss_res[ei] = ((uint64_t)dst << 8) | n_out;
                 if (n_out > 1) atomicAdd(&W.tile_extra[tile], n_out - 1);
                 done = true;
             }
@@ -1160,9 +1179,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeA
 // ---- final scatter -------------------------------------------------------------------------------------
 constexpr int kEmitPer = (kTileCap + 1 + kTileThreads - 1) / kTileThreads;  // items per thread
 constexpr int kEmitQueue = 128;
-__device__ __forceinline__ const SlowEntry& deferred_entry(const Workspace& W, int32_t item) {
+// (pool offset, token count) of a deferred pre-token
+__device__ __forceinline__ void deferred_result(const Workspace& W, int32_t item, uint64_t* pool_off, uint32_t* count) {
     const uint32_t e = (uint32_t)(-2 - item);
-    return e >= kSlowBase ? W.slow[e - kSlowBase] : W.miss[e];
+    if (e >= kSlowBase) {
+        *pool_off = W.slow[e - kSlowBase].pool_off;
+        *count = W.slow[e - kSlowBase].count;
+    } else {
+        const uint64_t r = W.miss_res[e];
+        *pool_off = r >> 8;
+        *count = (uint32_t)(r & 0xFFu);
+    }
 }
 __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeArgs A) {
     __shared__ uint32_t docinc[kEmitPer * kTileThreads + 1];
@@ -1194,12 +1221,15 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
     const int c0 = tid * kEmitPer;
     int32_t item[kEmitPer];
     uint32_t cnts[kEmitPer];
+    uint64_t poff[kEmitPer];
     uint32_t ntok = 0, ndoc = 0;
 #pragma unroll
     for (int j = 0; j < kEmitPer; j++) {
         const uint32_t i = c0 + j;
         item[j] = i < n_items ? in[i] : kDead;
-        cnts[j] = item[j] >= 0 ? 1u : (item[j] < kDead ? deferred_entry(W, item[j]).count : 0u);
+        cnts[j] = item[j] >= 0 ? 1u : 0u;
+        poff[j] = 0;
+        if (item[j] < kDead) deferred_result(W, item[j], &poff[j], &cnts[j]);
         ntok += cnts[j];
         if (i <= n_items) ndoc += docinc[i];
     }
@@ -1218,9 +1248,8 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
         if (item[j] >= 0) {
             A.out_tok[o] = item[j];
         } else {
-            const SlowEntry& se = deferred_entry(W, item[j]);
             if (cnts[j] <= 64) {
-                for (uint32_t k = 0; k < cnts[j]; k++) A.out_tok[o + k] = W.pool[se.pool_off + k];
+                for (uint32_t k = 0; k < cnts[j]; k++) A.out_tok[o + k] = W.pool[poff[j] + k];
             } else {
                 uint32_t qi = atomicAdd(&q_n, 1u);
                 if (qi < kEmitQueue) { q_out[qi] = o; q_item[qi] = item[j]; }
@@ -1240,9 +1269,10 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
     // tokens has more than 21 bytes, so one tile holds fewer than kEmitQueue of them)
     const uint32_t qn = q_n < kEmitQueue ? q_n : kEmitQueue;
     for (uint32_t qi = 0; qi < qn; qi++) {
-        const SlowEntry& se = deferred_entry(W, q_item[qi]);
+        uint64_t po; uint32_t cn;
+        deferred_result(W, q_item[qi], &po, &cn);
         const uint64_t o = q_out[qi];
-        for (uint32_t k = tid; k < se.count; k += kTileThreads) A.out_tok[o + k] = W.pool[se.pool_off + k];
+        for (uint32_t k = tid; k < cn; k += kTileThreads) A.out_tok[o + k] = W.pool[po + k];
     }
 }
 
@@ -1353,9 +1383,10 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         L3_LAUNCH_CHECK();
         L3_EV(kEvTile);
         {
-            uint64_t mgrid = (W.miss_cap + kMergeThreads - 1) / kMergeThreads;
-            if (mgrid > 4096) mgrid = 4096;
-            if (mgrid == 0) mgrid = 1;
+            uint64_t per = (W.miss_shard_cap + kMergeThreads - 1) / kMergeThreads;  // workgroups per shard
+            if (per > 32) per = 32;
+            if (per == 0) per = 1;
+            const uint64_t mgrid = per * kMissShards;
             hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)mgrid), dim3(kMergeThreads), 0, stream, T, W, A);
             L3_LAUNCH_CHECK();
         }
