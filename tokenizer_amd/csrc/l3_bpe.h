@@ -12,42 +12,50 @@
 
 namespace l3 {
 
-// (idA,idB) -> prio or kNoPrio, continuing from an already loaded first bucket
-L3_HD uint32_t pair_resolve(const Tables& t, uint64_t key, uint32_t b, PairBucket v) {
-    const uint32_t mask = (1u << t.pair_log2) - 1u;
-    for (;;) {
-        if ((v.s[0] >> 24) == key) return (uint32_t)(v.s[0] & 0xFFFFFFu);
-        if ((v.s[1] >> 24) == key) return (uint32_t)(v.s[1] & 0xFFFFFFu);
-        if (v.s[1] == kPairEmpty) return kNoPrio;  // bucket never overflowed
-        b = (b + 1u) & mask;
-        v = t.pair_buckets[b];
-    }
+// (idA,idB) -> prio or kNoPrio, given the key's two candidate buckets
+L3_HD uint32_t pair_pick(uint64_t key, const PairBucket& u, const PairBucket& v) {
+    uint32_t r = kNoPrio;
+    if ((u.s[0] >> 24) == key) r = (uint32_t)(u.s[0] & 0xFFFFFFu);
+    if ((u.s[1] >> 24) == key) r = (uint32_t)(u.s[1] & 0xFFFFFFu);
+    if ((v.s[0] >> 24) == key) r = (uint32_t)(v.s[0] & 0xFFFFFFu);
+    if ((v.s[1] >> 24) == key) r = (uint32_t)(v.s[1] & 0xFFFFFFu);
+    return r;
 }
 L3_HD uint32_t pair_prio(const Tables& t, uint32_t a, uint32_t b) {
     const uint64_t key = pair_key(a, b);
-    const uint32_t h = pair_hash(key, t.pair_log2);
-    return pair_resolve(t, key, h, t.pair_buckets[h]);
+    uint32_t b1, b2;
+    pair_hash2(key, t.pair_log2, &b1, &b2);
+    const PairBucket u = t.pair_buckets[b1];
+    const PairBucket v = t.pair_buckets[b2];
+    return pair_pick(key, u, v);
 }
-// two independent probes with both first-bucket loads in flight together
+// two independent probes: four loads in flight together
 L3_HD void pair_prio2(const Tables& t, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t* r0, uint32_t* r1) {
     const uint64_t k0 = pair_key(a0, b0), k1 = pair_key(a1, b1);
-    const uint32_t h0 = pair_hash(k0, t.pair_log2), h1 = pair_hash(k1, t.pair_log2);
-    const PairBucket v0 = t.pair_buckets[h0];
-    const PairBucket v1 = t.pair_buckets[h1];
-    *r0 = pair_resolve(t, k0, h0, v0);
-    *r1 = pair_resolve(t, k1, h1, v1);
+    uint32_t p0, q0, p1, q1;
+    pair_hash2(k0, t.pair_log2, &p0, &q0);
+    pair_hash2(k1, t.pair_log2, &p1, &q1);
+    const PairBucket u0 = t.pair_buckets[p0];
+    const PairBucket v0 = t.pair_buckets[q0];
+    const PairBucket u1 = t.pair_buckets[p1];
+    const PairBucket v1 = t.pair_buckets[q1];
+    *r0 = pair_pick(k0, u0, v0);
+    *r1 = pair_pick(k1, u1, v1);
 }
 
-// Probe of one candidate slot chain for a string of <= 12 bytes given as three zero-padded words.
+// Whole-string probe for a string of <= 12 bytes given as three zero-padded words: four independent slot loads.
 L3_HD int32_t vocab_lookup_short(const Tables& t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len) {
-    const uint32_t mask = (1u << t.vocab_log2) - 1u;
-    uint32_t s = vocab_hash_short(w0, w1, w2, len, t.vocab_log2);
-    for (;;) {
-        VocabSlot v = t.vocab_slots[s];
-        if (v.w[3] == kVocabEmpty) return -1;
-        if ((v.w[3] >> 17) == len && v.w[0] == w0 && v.w[1] == w1 && v.w[2] == w2) return (int32_t)(v.w[3] & 0x1FFFFu);
-        s = (s + 1u) & mask;
-    }
+    uint32_t b1, b2;
+    vocab_hash_short2(w0, w1, w2, len, t.vocab_log2, &b1, &b2);
+    const VocabSlot s0 = t.vocab_slots[2u * b1], s1 = t.vocab_slots[2u * b1 + 1u], s2 = t.vocab_slots[2u * b2],
+                    s3 = t.vocab_slots[2u * b2 + 1u];
+    const uint32_t tag_lo = len << 17;
+    int32_t r = -1;
+    if ((s0.w[3] & ~0x1FFFFu) == tag_lo && s0.w[0] == w0 && s0.w[1] == w1 && s0.w[2] == w2) r = (int32_t)(s0.w[3] & 0x1FFFFu);
+    if ((s1.w[3] & ~0x1FFFFu) == tag_lo && s1.w[0] == w0 && s1.w[1] == w1 && s1.w[2] == w2) r = (int32_t)(s1.w[3] & 0x1FFFFu);
+    if ((s2.w[3] & ~0x1FFFFu) == tag_lo && s2.w[0] == w0 && s2.w[1] == w1 && s2.w[2] == w2) r = (int32_t)(s2.w[3] & 0x1FFFFu);
+    if ((s3.w[3] & ~0x1FFFFu) == tag_lo && s3.w[0] == w0 && s3.w[1] == w1 && s3.w[2] == w2) r = (int32_t)(s3.w[3] & 0x1FFFFu);
+    return r;
 }
 
 // Whole-string lookup.  `get(i)` returns byte i of the (already expanded) pre-token, 0 <= i < len.
@@ -62,19 +70,17 @@ L3_HD int32_t vocab_lookup(const Tables& t, Get get, uint32_t len) {
     }
     StrHash h = strhash_init();
     for (uint32_t i = 0; i < len; i++) strhash_add(h, get(i));
-    const uint32_t mask = (1u << t.vocab_log2) - 1u;
-    uint32_t s = strhash_slot(h, len, t.vocab_log2);
-    for (;;) {
-        VocabSlot v = t.vocab_slots[s];
-        if (v.w[3] == kVocabEmpty) return -1;
-        if ((v.w[3] >> 17) == len && v.w[0] == h.h2) {
-            const uint8_t* blob = t.vocab_blob + v.w[1];
-            bool eq = true;
-            for (uint32_t i = 0; i < len && eq; i++) eq = blob[i] == get(i);
-            if (eq) return (int32_t)(v.w[3] & 0x1FFFFu);
-        }
-        s = (s + 1u) & mask;
+    uint32_t b[2];
+    strhash_buckets(h, len, t.vocab_log2, &b[0], &b[1]);
+    for (int k = 0; k < 4; k++) {
+        const VocabSlot v = t.vocab_slots[2u * b[k >> 1] + (uint32_t)(k & 1)];
+        if (v.w[3] == kVocabEmpty || (v.w[3] >> 17) != len || v.w[0] != h.h2) continue;
+        const uint8_t* blob = t.vocab_blob + v.w[1];
+        bool eq = true;
+        for (uint32_t i = 0; i < len && eq; i++) eq = blob[i] == get(i);
+        if (eq) return (int32_t)(v.w[3] & 0x1FFFFu);
     }
+    return -1;
 }
 
 // In-place greedy merge of the symbols at positions [s, e) of `sym` (id >= 0 live, -1 dead) with the

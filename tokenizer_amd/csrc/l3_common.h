@@ -29,32 +29,37 @@ constexpr int kMaxTokenBytes = 128; // longest vocabulary entry (raw bytes)
 constexpr uint32_t kNoPrio = 0xFFFFFFFFu;
 L3_HD uint32_t prio_merged_id(uint32_t prio) { return prio >> 7; }
 
-// ---- pair table: (idA,idB) -> prio, open addressing over 16-byte buckets of two 8-byte slots ---
-// slot = key34 << 24 | prio24 ; empty = ~0.  key34 = idA << 17 | idB.  A bucket is filled slot 0
-// first; a key that finds its bucket full goes to the next bucket (linear probing over buckets), so a
-// lookup that sees an empty slot 1 can stop.  One 16-byte load answers almost every probe.
+// ---- pair table: (idA,idB) -> prio, two-choice (cuckoo) hashing over 16-byte buckets of two slots ---------
+// slot = key34 << 24 | prio24 ; empty = ~0.  key34 = idA << 17 | idB.  Every key lives in one of its two
+// candidate buckets, so a probe is two independent 16-byte loads and never a dependent chain: what a
+// wave pays is one memory latency, whatever its 64 lanes look up.
 constexpr uint64_t kPairEmpty = ~0ull;
 struct alignas(16) PairBucket { uint64_t s[2]; };
 L3_HD uint64_t pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << 17) | (uint64_t)b; }
-L3_HD uint32_t pair_hash(uint64_t key, uint32_t log2_buckets) {
-    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2_buckets));
+L3_HD void pair_hash2(uint64_t key, uint32_t log2_buckets, uint32_t* b1, uint32_t* b2) {
+    *b1 = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2_buckets));
+    *b2 = (uint32_t)(((key ^ (key >> 15)) * 0xD6E8FEB86659FD93ull) >> (64 - log2_buckets));
 }
 
-// ---- vocabulary table: raw token bytes -> id, open addressing, 16-byte slots ------------------
-// w[3] = id | len << 17 ; len <= 12: w[0..2] hold the bytes (little endian, zero padded);
-// len > 12: w[0] = second hash, w[1] = offset of the bytes in the blob, w[2] = 0.
-// empty slot: w[3] = 0xFFFFFFFF.
+// ---- vocabulary table: raw token bytes -> id, two-choice (cuckoo) hashing, 32-byte buckets of two slots --
+// slot: w[3] = id | len << 17 ; len <= 12: w[0..2] hold the bytes (little endian, zero padded);
+// len > 12: w[0] = second hash, w[1] = offset of the bytes in the blob, w[2] = 0.  empty: w[3] = 0xFFFFFFFF.
 struct alignas(16) VocabSlot { uint32_t w[4]; };
 constexpr uint32_t kVocabEmpty = 0xFFFFFFFFu;
 constexpr int kVocabInline = 12;
+L3_HD uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
 // short strings (<= 12 bytes) hash their three little-endian words directly
-L3_HD uint32_t vocab_hash_short(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len, uint32_t log2_slots) {
+L3_HD void vocab_hash_short2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len, uint32_t log2_buckets, uint32_t* b1,
+                             uint32_t* b2) {
     uint32_t x = w0 * 0x9E3779B1u;
     x = (x ^ (x >> 15)) + w1 * 0x85EBCA6Bu;
     x = (x ^ (x >> 13)) + w2 * 0xC2B2AE35u;
     x ^= len * 0x27D4EB2Fu;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x >> (32 - log2_slots);
+    *b1 = mix32(x) >> (32 - log2_buckets);
+    *b2 = mix32(x * 0x2C1B3C6Du + 0x297A2D39u) >> (32 - log2_buckets);
 }
 // longer strings: two running FNV-1a style hashes over the (expanded) pre-token bytes
 struct StrHash { uint32_t h1, h2; };
@@ -63,10 +68,9 @@ L3_HD void strhash_add(StrHash& h, uint32_t byte) {
     h.h1 = (h.h1 ^ byte) * 16777619u;
     h.h2 = (h.h2 + byte + 1u) * 0x85EBCA6Bu; h.h2 ^= h.h2 >> 15;
 }
-L3_HD uint32_t strhash_slot(const StrHash& h, uint32_t len, uint32_t log2_slots) {
-    uint32_t x = h.h1 ^ (len * 0x9E3779B1u);
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x >> (32 - log2_slots);
+L3_HD void strhash_buckets(const StrHash& h, uint32_t len, uint32_t log2_buckets, uint32_t* b1, uint32_t* b2) {
+    *b1 = mix32(h.h1 ^ (len * 0x9E3779B1u)) >> (32 - log2_buckets);
+    *b2 = mix32(h.h2 + len * 0x85EBCA6Bu + 0x68E31DA4u) >> (32 - log2_buckets);
 }
 
 // ---- character classes ------------------------------------------------------------------------
@@ -81,7 +85,7 @@ struct Tables {
     const uint8_t* byte_tok;      // [256] token id of each single byte (ids 0..255)
     const uint32_t* bytepair;     // [65536] prio of (byte a, byte b) indexed a<<8|b, kNoPrio if no rule
     const PairBucket* pair_buckets;  // [1 << pair_log2]
-    const VocabSlot* vocab_slots; // [1 << vocab_log2]
+    const VocabSlot* vocab_slots; // [2 << vocab_log2]: bucket b = slots 2b, 2b+1
     const uint8_t* vocab_blob;    // raw bytes of tokens longer than kVocabInline
     const int32_t* special_id;    // [256] canonical special index -> token id (0 = not a token)
     uint32_t pair_log2;

@@ -69,7 +69,7 @@ struct Workspace {
     int32_t* stream;        // [n_tiles * kTileCap] per-tile token stream incl. slow placeholders
     uint32_t* tile_items;   // [n_tiles] items in the tile's stream
     uint32_t* tile_extra;   // [n_tiles] sum of (tokens - 1) over the tile's deferred pre-tokens (atomic adds)
-    uint64_t* tile_base;    // [n_tiles + 1] exclusive scan of the tile token totals
+    uint64_t* tile_base;    // [ceil(n_tiles / 1024)] exclusive scan of the token totals of blocks of 1024 tiles
     uint32_t* tile_doc0;    // [n_tiles + 1] first document whose start is >= the tile start
     uint32_t* doc_item;     // [n_docs + 1] stream index (inside its tile) of the document's first item
     SlowEntry* slow;        // [slow_cap]

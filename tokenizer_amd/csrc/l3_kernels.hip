@@ -46,13 +46,14 @@ __device__ __forceinline__ uint32_t wave_iscan(uint32_t v) {
     return v;
 }
 // exclusive sum scan over the workgroup; tmp: >= 4 words of LDS.  Contains two barriers.
+template <int NW = kTileThreads / 64>
 __device__ __forceinline__ uint32_t block_escan(uint32_t v, uint32_t* tmp, uint32_t* total) {
     uint32_t inc = wave_iscan(v);
     if (lane_id() == 63) tmp[wave_id()] = inc;
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < kTileThreads / 64; i++) {
+    for (int i = 0; i < NW; i++) {
         uint32_t x = tmp[i];
         if (i < wave_id()) base += x;
         tot += x;
@@ -61,6 +62,7 @@ __device__ __forceinline__ uint32_t block_escan(uint32_t v, uint32_t* tmp, uint3
     *total = tot;
     return base + inc - v;
 }
+template <int NW = kTileThreads / 64>
 __device__ __forceinline__ unsigned long long block_min64(unsigned long long v, unsigned long long* tmp) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -71,7 +73,7 @@ __device__ __forceinline__ unsigned long long block_min64(unsigned long long v, 
     __syncthreads();
     unsigned long long r = tmp[0];
 #pragma unroll
-    for (int i = 1; i < kTileThreads / 64; i++) r = tmp[i] < r ? tmp[i] : r;
+    for (int i = 1; i < NW; i++) r = tmp[i] < r ? tmp[i] : r;
     __syncthreads();
     return r;
 }
@@ -792,8 +794,13 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
 // Every lane runs the greedy merge loop (bpe.go:36-71) of one pre-token of <= kLaneMax bytes on its own span
 // of a shared LDS symbol array (spans laid out by a prefix sum of the lengths), so all 64 lanes of a wave
 // keep independent probe chains in flight.
-constexpr int kMergeThreads = 256;
-constexpr int kMergeSyms = 4096;
+#ifndef L3_MERGE_THREADS
+#define L3_MERGE_THREADS 256
+#define L3_MERGE_SYMS 4096
+#endif
+constexpr int kMergeThreads = L3_MERGE_THREADS;
+constexpr int kMergeSyms = L3_MERGE_SYMS;
+constexpr int kMergeWaves = kMergeThreads / 64;
 __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspace W, EncodeArgs A) {
     __shared__ int32_t sym[kMergeSyms];
     __shared__ uint32_t pr[kMergeSyms];
@@ -803,7 +810,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
     __shared__ unsigned long long pool_base;
     if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x;
-    byte_tok[tid] = T.byte_tok[tid];
+    for (int i = tid; i < 256; i += kMergeThreads) byte_tok[i] = T.byte_tok[i];
     const uint32_t shard = blockIdx.x % kMissShards;
     uint64_t n_ent = W.status->miss_count[shard];
     if (n_ent > W.miss_shard_cap) n_ent = W.miss_shard_cap;
@@ -817,7 +824,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
         uint32_t len = 0, tile = 0;
         if (have) { const MissIn mi = W.miss_in[ei]; start = mi.start; len = mi.len; tile = mi.tile; }
         uint32_t total;
-        const uint32_t off = block_escan(len, tmp, &total);
+        const uint32_t off = block_escan<kMergeWaves>(len, tmp, &total);
         bool done = !have || len == 0;
         uint32_t base = 0, n_out = 0;
         int32_t toks[4];  // first tokens kept in registers until the pool slot is known; the rest re-read from LDS
@@ -839,13 +846,13 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
                     for (int j = 0; j < 8; j++)
                         if (i + j < (int)len) { sym[s + i + j] = byte_tok[bb[j]]; pr[s + i + j] = pp[j]; }
                 }
-                merge_span(T, sym, pr, s, e);
+                if (!(A.flags & 0x100u)) merge_span(T, sym, pr, s, e);
                 n_out = 0;
                 for (int i = s; i < e; i++) n_out += sym[i] >= 0 ? 1u : 0u;
             }
             // pool space for this window's tokens: one atomic per workgroup
             uint32_t wtot;
-            const uint32_t po = block_escan(act ? n_out : 0u, tmp, &wtot);
+            const uint32_t po = block_escan<kMergeWaves>(act ? n_out : 0u, tmp, &wtot);
             if (tid == 0) pool_base = wtot ? atomicAdd(&W.status->pool_used, (unsigned long long)wtot) : 0ull;
             __syncthreads();
             if (act) {
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
                 if (n_out > 1) atomicAdd(&W.tile_extra[tile], n_out - 1);
                 done = true;
             }
-            const unsigned long long nxt = block_min64(done ? ~0ull : (unsigned long long)off, tmp64);
+            const unsigned long long nxt = block_min64<kMergeWaves>(done ? ~0ull : (unsigned long long)off, tmp64);
             if (nxt == ~0ull) break;
             base = (uint32_t)nxt;
         }
@@ -1135,19 +1142,34 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
     }
 }
 
-// ---- scan of per-tile totals ----------------------------------------------------------------------
+// ---- per-tile output bases: block totals, scan of the block totals -----------------------------------------
 constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeArgs A, uint64_t n_tiles) {
+constexpr int kScanBlock = 1024;  // tiles per block total
+__global__ __launch_bounds__(256) void block_totals_kernel(Workspace W, uint64_t n_tiles) {
+    __shared__ unsigned long long red[4];
+    if (W.status->flags & kBadOffsets) return;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kScanBlock;
+    unsigned long long v = 0;
+    for (int j = 0; j < kScanBlock / 256; j++) {
+        uint64_t t = t0 + (uint64_t)j * 256 + threadIdx.x;
+        if (t < n_tiles) v += (unsigned long long)W.tile_items[t] + W.tile_extra[t];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane_id() == 0) red[wave_id()] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) W.tile_base[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeArgs A, uint64_t n_blocks) {
     __shared__ unsigned long long wsum[kScanThreads / 64];
     __shared__ unsigned long long carry_s;
     if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint64_t base = 0; base < n_tiles; base += kScanThreads) {
+    for (uint64_t base = 0; base < n_blocks; base += kScanThreads) {
         uint64_t t = base + tid;
-        unsigned long long v = 0;
-        if (t < n_tiles) v = (unsigned long long)W.tile_items[t] + W.tile_extra[t];
+        unsigned long long v = t < n_blocks ? W.tile_base[t] : 0ull;
         unsigned long long inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1161,14 +1183,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeA
             if (i < (tid >> 6)) pre += wsum[i];
             tot += wsum[i];
         }
-        if (t < n_tiles) W.tile_base[t] = pre + inc - v;
+        if (t < n_blocks) W.tile_base[t] = pre + inc - v;
         __syncthreads();
         if (tid == 0) carry_s += tot;
         __syncthreads();
     }
     if (tid == 0) {
         unsigned long long total = carry_s;
-        W.tile_base[n_tiles] = total;
         uint32_t be = (A.flags & 1u) + ((A.flags >> 1) & 1u);
         total += (unsigned long long)A.n_docs * be;
         W.status->total_tokens = total;
@@ -1177,7 +1198,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeA
 }
 
 // ---- final scatter -------------------------------------------------------------------------------------
-constexpr int kEmitPer = (kTileCap + 1 + kTileThreads - 1) / kTileThreads;  // items per thread
 constexpr int kEmitQueue = 128;
 // (pool offset, token count) of a deferred pre-token
 __device__ __forceinline__ void deferred_result(const Workspace& W, int32_t item, uint64_t* pool_off, uint32_t* count) {
@@ -1191,10 +1211,31 @@ __device__ __forceinline__ void deferred_result(const Workspace& W, int32_t item
         *count = (uint32_t)(r & 0xFFu);
     }
 }
+// exclusive scan of two 32-bit counters packed in one 64-bit word; tmp: >= 4 words.  Two barriers.
+__device__ __forceinline__ unsigned long long block_escan64(unsigned long long v, unsigned long long* tmp, unsigned long long* total) {
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane_id() >= d) inc += o;
+    }
+    if (lane_id() == 63) tmp[wave_id()] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kTileThreads / 64; i++) {
+        unsigned long long x = tmp[i];
+        if (i < wave_id()) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
 __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeArgs A) {
-    __shared__ uint32_t docinc[kEmitPer * kTileThreads + 1];
-    __shared__ uint32_t tokpre[kEmitPer * kTileThreads + 1];
-    __shared__ uint32_t tmp[16];
+    __shared__ uint32_t docinc[kTileCap + 1];
+    __shared__ uint32_t tokpre[kTileCap + 1];
+    __shared__ unsigned long long tmp64[8];
     __shared__ unsigned long long q_out[kEmitQueue];
     __shared__ int32_t q_item[kEmitQueue];
     __shared__ uint32_t q_n;
@@ -1209,53 +1250,54 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
     const uint64_t d_lo = W.tile_doc0[tile];
     const uint64_t d_hi = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
     const uint32_t bos = A.flags & 1u, eos = (A.flags >> 1) & 1u, be = bos + eos;
-    const uint64_t base = W.tile_base[tile];
     const int32_t* in = W.stream + tile * (uint64_t)kTileCap;
 
-    for (int i = tid; i < kEmitPer * kTileThreads + 1; i += kTileThreads) docinc[i] = 0;
+    for (int i = tid; i <= (int)n_items; i += kTileThreads) docinc[i] = 0;
     if (tid == 0) q_n = 0;
-    __syncthreads();
+    // tokens before this tile: scanned block base + the tiles of the block that precede it
+    unsigned long long base;
+    {
+        const uint64_t blk = tile / kScanBlock, t0 = blk * kScanBlock;
+        unsigned long long v = 0;
+        for (uint64_t t = t0 + tid; t < tile; t += kTileThreads) v += (unsigned long long)W.tile_items[t] + W.tile_extra[t];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane_id() == 0) tmp64[4 + wave_id()] = v;
+        __syncthreads();
+        base = W.tile_base[blk] + tmp64[4] + tmp64[5] + tmp64[6] + tmp64[7];
+    }
     for (uint64_t d = d_lo + tid; d < d_hi; d += kTileThreads) atomicAdd(&docinc[W.doc_item[d]], 1u);
     __syncthreads();
 
-    const int c0 = tid * kEmitPer;
-    int32_t item[kEmitPer];
-    uint32_t cnts[kEmitPer];
-    uint64_t poff[kEmitPer];
-    uint32_t ntok = 0, ndoc = 0;
-#pragma unroll
-    for (int j = 0; j < kEmitPer; j++) {
-        const uint32_t i = c0 + j;
-        item[j] = i < n_items ? in[i] : kDead;
-        cnts[j] = item[j] >= 0 ? 1u : 0u;
-        poff[j] = 0;
-        if (item[j] < kDead) deferred_result(W, item[j], &poff[j], &cnts[j]);
-        ntok += cnts[j];
-        if (i <= n_items) ndoc += docinc[i];
-    }
-    uint32_t t_doc, t_tok;
-    uint32_t tp = block_escan(ntok, tmp, &t_tok);
-    uint32_t dp = block_escan(ndoc, tmp, &t_doc);
-#pragma unroll
-    for (int j = 0; j < kEmitPer; j++) {
-        const uint32_t i = c0 + j;
-        if (i > n_items) break;
-        dp += docinc[i];  // documents that start at or before item i
-        tokpre[i] = tp;
-        if (i == n_items) break;
-        const uint64_t D = d_lo + dp - 1;
-        const uint64_t o = base + tp + D * be + bos;
-        if (item[j] >= 0) {
-            A.out_tok[o] = item[j];
-        } else {
-            if (cnts[j] <= 64) {
-                for (uint32_t k = 0; k < cnts[j]; k++) A.out_tok[o + k] = W.pool[poff[j] + k];
+    // items in rounds of one per thread (coalesced); running token / document prefixes carried across rounds
+    unsigned long long carry = 0;  // low 32: tokens, high 32: documents started
+    const uint32_t rounds = (n_items + 1 + kTileThreads - 1) / kTileThreads;
+#pragma unroll 1
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = r * kTileThreads + tid;
+        const int32_t item = i < n_items ? in[i] : kDead;
+        uint32_t cnt = item >= 0 ? 1u : 0u;
+        uint64_t poff = 0;
+        if (item < kDead) deferred_result(W, item, &poff, &cnt);
+        const uint32_t dinc = i <= n_items ? docinc[i] : 0u;
+        unsigned long long tot;
+        const unsigned long long ex = carry + block_escan64(((unsigned long long)dinc << 32) | cnt, tmp64, &tot);
+        carry += tot;
+        const uint32_t tp = (uint32_t)ex;
+        const uint32_t dp = (uint32_t)(ex >> 32) + dinc;  // documents that start at or before item i
+        if (i <= n_items) tokpre[i] = tp;
+        if (i < n_items) {
+            const uint64_t D = d_lo + dp - 1;
+            const uint64_t o = base + tp + D * be + bos;
+            if (item >= 0) {
+                A.out_tok[o] = item;
+            } else if (cnt <= 64) {
+                for (uint32_t k = 0; k < cnt; k++) A.out_tok[o + k] = W.pool[poff + k];
             } else {
                 uint32_t qi = atomicAdd(&q_n, 1u);
-                if (qi < kEmitQueue) { q_out[qi] = o; q_item[qi] = item[j]; }
+                if (qi < kEmitQueue) { q_out[qi] = o; q_item[qi] = item; }
             }
         }
-        tp += cnts[j];
     }
     __syncthreads();
     // per-document offsets, BOS / EOS (tokenizer.go:225-229,258-262)
@@ -1396,7 +1438,10 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A);
         L3_LAUNCH_CHECK();
         L3_EV(kEvSlow);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, W, A, n_tiles);
+        const uint64_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
+        hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks), dim3(256), 0, stream, W, n_tiles);
+        L3_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, W, A, n_blocks);
         L3_LAUNCH_CHECK();
         L3_EV(kEvScan);
     }

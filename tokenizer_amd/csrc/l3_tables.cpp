@@ -196,50 +196,98 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
     }
     T.n_merges = (int)rules.size();
 
-    // pair hash table (two-slot buckets) + direct byte-pair table
-    T.pair_log2 = 15;
-    while ((2ull << T.pair_log2) < rules.size() * 3) T.pair_log2++;  // load factor <= 1/3
-    T.pair_buckets.assign(1ull << T.pair_log2, PairBucket{{kPairEmpty, kPairEmpty}});
+    // direct byte-pair table
     T.bytepair.assign(65536, kNoPrio);
     uint8_t tok_byte[256];  // id -> byte for ids 0..255
     for (int b = 0; b < 256; b++) tok_byte[T.byte_tok[b]] = (uint8_t)b;
-    const uint32_t mask = (1u << T.pair_log2) - 1;
-    for (const Rule& r : rules) {
-        uint32_t prio = (r.merged << 7) | r.sub;
-        uint64_t key = pair_key(r.a, r.b);
-        uint32_t b = pair_hash(key, T.pair_log2);
-        while (T.pair_buckets[b].s[1] != kPairEmpty) b = (b + 1) & mask;
-        PairBucket& pb = T.pair_buckets[b];
-        pb.s[pb.s[0] == kPairEmpty ? 0 : 1] = (key << 24) | prio;
-        if (r.a < 256 && r.b < 256) T.bytepair[((uint32_t)tok_byte[r.a] << 8) | tok_byte[r.b]] = prio;
+    for (const Rule& r : rules)
+        if (r.a < 256 && r.b < 256) T.bytepair[((uint32_t)tok_byte[r.a] << 8) | tok_byte[r.b]] = (r.merged << 7) | r.sub;
+
+    // ---- pair table: cuckoo placement into two-slot buckets
+    uint64_t rng = 0x243F6A8885A308D3ull;
+    auto next_rand = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    for (T.pair_log2 = 15;; T.pair_log2++) {
+        if ((2ull << T.pair_log2) * 5 < rules.size() * 9) continue;  // load factor <= 5/9
+        T.pair_buckets.assign(1ull << T.pair_log2, PairBucket{{kPairEmpty, kPairEmpty}});
+        bool ok = true;
+        for (const Rule& r : rules) {
+            uint64_t item = (pair_key(r.a, r.b) << 24) | ((r.merged << 7) | r.sub);
+            bool placed = false;
+            for (int kick = 0; kick < 1000 && !placed; kick++) {
+                uint32_t b[2];
+                pair_hash2(item >> 24, T.pair_log2, &b[0], &b[1]);
+                for (int k = 0; k < 4 && !placed; k++) {
+                    uint64_t& slot = T.pair_buckets[b[k >> 1]].s[k & 1];
+                    if (slot == kPairEmpty) { slot = item; placed = true; }
+                }
+                if (!placed) {  // evict a random resident of one of the two buckets and re-place it
+                    uint64_t rr = next_rand();
+                    uint64_t& slot = T.pair_buckets[b[rr & 1]].s[(rr >> 1) & 1];
+                    std::swap(slot, item);
+                }
+            }
+            if (!placed) { ok = false; break; }
+        }
+        if (ok) break;
+        if (T.pair_log2 > 24) { T.error = "pair table placement failed"; return false; }
     }
 
-    // ---- whole-string vocabulary table (bpe.go:27-33 looks the whole pre-token up first)
-    T.vocab_log2 = 16;
-    while ((1u << T.vocab_log2) < (uint32_t)n_base * 2u) T.vocab_log2++;
-    T.vocab_slots.assign(1u << T.vocab_log2, VocabSlot{{0, 0, 0, kVocabEmpty}});
+    // ---- whole-string vocabulary table (bpe.go:27-33 looks the whole pre-token up first): cuckoo as well
     T.vocab_blob.clear();
-    const uint32_t vmask = (1u << T.vocab_log2) - 1;
+    std::vector<VocabSlot> items;
+    items.reserve(by_bytes.size());
     for (auto& kv : by_bytes) {
         const std::string& s = kv.first;
         uint32_t len = (uint32_t)s.size();
         if (len == 0 || len > (uint32_t)kMaxTokenBytes) { T.error = "vocabulary entry longer than 128 bytes"; return false; }
-        StrHash h = strhash_init();
-        for (unsigned char c : s) strhash_add(h, c);
         VocabSlot slot{{0, 0, 0, (uint32_t)kv.second | (len << 17)}};
         if (len <= (uint32_t)kVocabInline) {
             for (uint32_t k = 0; k < len; k++) slot.w[k >> 2] |= (uint32_t)(uint8_t)s[k] << ((k & 3) * 8);
         } else {
+            StrHash h = strhash_init();
+            for (unsigned char c : s) strhash_add(h, c);
             slot.w[0] = h.h2;
             slot.w[1] = (uint32_t)T.vocab_blob.size();
             T.vocab_blob.insert(T.vocab_blob.end(), s.begin(), s.end());
         }
-        uint32_t p = len <= (uint32_t)kVocabInline ? vocab_hash_short(slot.w[0], slot.w[1], slot.w[2], len, T.vocab_log2)
-                                                   : strhash_slot(h, len, T.vocab_log2);
-        while (T.vocab_slots[p].w[3] != kVocabEmpty) p = (p + 1) & vmask;
-        T.vocab_slots[p] = slot;
+        items.push_back(slot);
     }
     while (T.vocab_blob.size() % 16) T.vocab_blob.push_back(0);
+    std::sort(items.begin(), items.end(), [](const VocabSlot& a, const VocabSlot& b) { return (a.w[3] & 0x1FFFFu) < (b.w[3] & 0x1FFFFu); });
+    auto vbuckets = [&](const VocabSlot& v, uint32_t* b) {
+        uint32_t len = v.w[3] >> 17;
+        if (len <= (uint32_t)kVocabInline) {
+            vocab_hash_short2(v.w[0], v.w[1], v.w[2], len, T.vocab_log2, &b[0], &b[1]);
+        } else {
+            StrHash h = strhash_init();
+            for (uint32_t k = 0; k < len; k++) strhash_add(h, T.vocab_blob[v.w[1] + k]);
+            strhash_buckets(h, len, T.vocab_log2, &b[0], &b[1]);
+        }
+    };
+    for (T.vocab_log2 = 14;; T.vocab_log2++) {
+        if ((2ull << T.vocab_log2) < items.size() * 2) continue;  // load factor <= 1/2
+        T.vocab_slots.assign(2ull << T.vocab_log2, VocabSlot{{0, 0, 0, kVocabEmpty}});
+        bool ok = true;
+        for (VocabSlot item : items) {
+            bool placed = false;
+            for (int kick = 0; kick < 1000 && !placed; kick++) {
+                uint32_t b[2];
+                vbuckets(item, b);
+                for (int k = 0; k < 4 && !placed; k++) {
+                    VocabSlot& slot = T.vocab_slots[2ull * b[k >> 1] + (k & 1)];
+                    if (slot.w[3] == kVocabEmpty) { slot = item; placed = true; }
+                }
+                if (!placed) {
+                    uint64_t rr = next_rand();
+                    VocabSlot& slot = T.vocab_slots[2ull * b[rr & 1] + ((rr >> 1) & 1)];
+                    std::swap(slot, item);
+                }
+            }
+            if (!placed) { ok = false; break; }
+        }
+        if (ok) break;
+        if (T.vocab_log2 > 24) { T.error = "vocabulary table placement failed"; return false; }
+    }
 
     build_class_tables(T);
     return true;
