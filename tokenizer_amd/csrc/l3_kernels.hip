@@ -264,7 +264,7 @@ __global__ void docs_kernel(Workspace W, EncodeArgs A, uint64_t n_tiles) {
 constexpr int kWords = kRegion / 64;
 static_assert(kWords * 64 == kRegion && kWords <= 64, "one wave must hold one mask word per lane");
 typedef unsigned long long u64;
-enum { B_RS = 0, B_L, B_N, B_NL, B_SP, B_WS, B_INV, B_APOS, B_STMD, B_R, B_E, B_V, B_LL, B_NX,
+enum { B_RS = 0, B_L, B_N, B_NL, B_SP, B_WS, B_INV, B_APOS, B_NX, B_CE2, B_CE3,
        B_DS, B_SPS, B_SPB, B_SPE, B_ST, B_CONTN, B_COUNT };
 
 struct TileLds {
@@ -349,8 +349,8 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
               WS = L3_LD(B_WS) & nspb;
     const u64 P = RS & ~(L | N | NL | SP | WS);
     const u64 SEG = L3_LD(B_DS) | L3_LD(B_SPE);
-    const u64 APOS = L3_LD(B_APOS) & nspb, STMD = L3_LD(B_STMD) & nspb, cR = L3_LD(B_R) & nspb, cE = L3_LD(B_E) & nspb,
-              cV = L3_LD(B_V) & nspb, cLL = L3_LD(B_LL) & nspb;
+    // CE2 / CE3: a letter pattern of a contraction ('s 't 'm 'd | 're 've 'll) ends right before this byte
+    const u64 APOS = L3_LD(B_APOS) & nspb, CE2 = L3_LD(B_CE2), CE3 = L3_LD(B_CE3);
     const u64 NX = L3_LD(B_NX) & nspb;
     const u64 cont = ~RS;
     // class of the rune that CONTAINS each byte (classes smeared over continuation bytes)
@@ -387,24 +387,19 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
         sQ |= ((sQ << 1) | (u & 1u)) & cont;
     }
     u64 p_Q;
-    u64 AS2, AS3, STMD1, SEG1, SEG2, R2, E1, V2, LL1, LL2;
+    u64 AS2, AS3, SEG1, SEG2;
     {
         // top three bits of the previous word of every mask that is shifted by up to 3
-        uint32_t t = (uint32_t)(AS >> 61) | ((uint32_t)(SEG >> 61) << 3) | ((uint32_t)(cR >> 61) << 6) | ((uint32_t)(cV >> 61) << 9) |
-                     ((uint32_t)(cLL >> 61) << 12) | ((uint32_t)(STMD >> 61) << 15) | ((uint32_t)(cE >> 61) << 18) |
-                     ((uint32_t)(sQ >> 61) << 21);
+        uint32_t t = (uint32_t)(AS >> 61) | ((uint32_t)(SEG >> 61) << 3) | ((uint32_t)(sQ >> 61) << 6);
         uint32_t u = up32(t);
 #define L3_SHL(X, k, f) (((X) << (k)) | (u64)((((u) >> (f)) & 7u) >> (3 - (k))))
         AS2 = L3_SHL(AS, 2, 0); AS3 = L3_SHL(AS, 3, 0);
         SEG1 = L3_SHL(SEG, 1, 3); SEG2 = L3_SHL(SEG, 2, 3);
-        R2 = L3_SHL(cR, 2, 6); V2 = L3_SHL(cV, 2, 9);
-        LL1 = L3_SHL(cLL, 1, 12); LL2 = L3_SHL(cLL, 2, 12);
-        STMD1 = L3_SHL(STMD, 1, 15); E1 = L3_SHL(cE, 1, 18);
-        p_Q = L3_SHL(sQ, 1, 21);
+        p_Q = L3_SHL(sQ, 1, 6);
 #undef L3_SHL
     }
-    const u64 ce2 = AS2 & STMD1 & ~SEG1;
-    const u64 ce3 = AS3 & ((R2 & E1) | (V2 & E1) | (LL2 & LL1)) & ~SEG2 & ~SEG1;
+    const u64 ce2 = AS2 & CE2 & ~SEG1;
+    const u64 ce3 = AS3 & CE3 & ~SEG2 & ~SEG1;
     const u64 startL = L & (p_N | p_NL | p_Q | (p_L & (ce2 | ce3)));
     const u64 startP = P & (p_L | p_N | p_WS | p_NL);
     // white space: the look-ahead "followed by a non-space rune of the same segment"
@@ -507,24 +502,25 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     const int eval_hi = hard ? n : n - kEvalSlack;
     const uint32_t d0 = W.tile_doc0[tile];
 
-    // -- stage bytes, clear what is accumulated with atomics
+    // -- stage bytes (16 per thread), clear what is accumulated with atomics
     for (int i = tid; i < kWords + 2; i += kTileThreads) {
-        R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0;
+        R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0; R.bm[B_CE2][i] = 0; R.bm[B_CE3][i] = 0;
     }
     if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; }
-    {
-        const uint8_t* srcp = A.text + g_lo;
-        const bool aligned = (((uintptr_t)srcp) & 15u) == 0;
-        for (int g = tid; g * 16 < n + 16; g += kTileThreads) {
-            int o = g * 16;
-            if (aligned && o + 16 <= n) {
-                *reinterpret_cast<uint4*>(&R.b[o]) = *reinterpret_cast<const uint4*>(srcp + o);
-            } else {
-                for (int k = 0; k < 16; k++)
-                    if (o + k < kRegion + 16) R.b[o + k] = (o + k < n) ? srcp[o + k] : (uint8_t)0;
-            }
+    const int c0 = tid * 16;            // region bytes [c0, c0 + 16) are classified by this thread
+    const bool cls_thread = tid < kRegion / 16;
+    uint32_t xw[4] = {0, 0, 0, 0};
+    if (cls_thread && c0 < n) {
+        const uint8_t* srcp = A.text + g_lo + c0;
+        if (c0 + 16 <= n && (((uintptr_t)srcp) & 15u) == 0) {
+            const uint4 v = *reinterpret_cast<const uint4*>(srcp);
+            xw[0] = v.x; xw[1] = v.y; xw[2] = v.z; xw[3] = v.w;
+        } else {
+            for (int k = 0; k < 16 && c0 + k < n; k++) xw[k >> 2] |= (uint32_t)srcp[k] << ((k & 3) * 8);
         }
     }
+    if (cls_thread) *reinterpret_cast<uint4*>(&R.b[c0]) = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+    if (tid == 0) *reinterpret_cast<uint4*>(&R.b[kRegion]) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (tid == 0 && d0 > 0) {
         uint64_t pos = A.doc_off[d0 - 1];
@@ -535,43 +531,74 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         if (pos >= g_hi) break;
         atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
     }
+    // -- ASCII bytes: classes of four bytes at a time (bit 7 of every byte of a word = the property)
+    uint32_t m_rs = 0, m_l = 0, m_n = 0, m_nl = 0, m_sp = 0, m_ws = 0, m_apos = 0, m_lt = 0;
+    if (cls_thread) {
+        const uint32_t valid = c0 + 16 <= n ? 0xFFFFu : (c0 < n ? (1u << (n - c0)) - 1u : 0u);
+        // gathers bit 7 of the four bytes of m into bits 0..3
+        auto mm = [](uint32_t m) {
+            uint32_t y = m >> 7;
+            y |= y >> 7;
+            y |= y >> 14;
+            return y & 0xFu;
+        };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = xw[k];
+            const uint32_t asc = ~w & 0x80808080u;
+            const uint32_t t7 = w & 0x7F7F7F7Fu;
+            const uint32_t f = t7 | 0x20202020u;
+#define L3_GE(x, c) (((x) + (0x80u - (uint32_t)(c)) * 0x01010101u) & 0x80808080u)
+#define L3_EQ(x, c) (~(((x) ^ ((uint32_t)(c) * 0x01010101u)) + 0x7F7F7F7Fu) & 0x80808080u)
+            const uint32_t cl = L3_GE(f, 'a') & ~L3_GE(f, 'z' + 1) & asc;
+            const uint32_t cn = L3_GE(t7, '0') & ~L3_GE(t7, '9' + 1) & asc;
+            const uint32_t csp = L3_EQ(t7, ' ') & asc;
+            const uint32_t cnl = (L3_EQ(t7, '\n') | L3_EQ(t7, '\r')) & asc;
+            const uint32_t cws = L3_GE(t7, 9) & ~L3_GE(t7, 14) & asc & ~cnl;
+            const uint32_t cap = L3_EQ(t7, '\'') & asc;
+            const uint32_t clt = L3_EQ(t7, '<') & asc;
+#undef L3_GE
+#undef L3_EQ
+            m_rs |= mm(asc) << (4 * k); m_l |= mm(cl) << (4 * k); m_n |= mm(cn) << (4 * k); m_nl |= mm(cnl) << (4 * k);
+            m_sp |= mm(csp) << (4 * k); m_ws |= mm(cws) << (4 * k); m_apos |= mm(cap) << (4 * k); m_lt |= mm(clt) << (4 * k);
+        }
+        m_rs &= valid; m_l &= valid; m_n &= valid; m_nl &= valid; m_sp &= valid; m_ws &= valid; m_apos &= valid; m_lt &= valid;
+    }
     __syncthreads();
 
-    // -- per-byte properties as ballots (state_machine.go:36,310-320), special-token literals (special.go:12)
+    // -- bytes outside ASCII (generic UTF-8 decode + class table), contraction letters after an apostrophe,
+    //    special-token literals after '<' (state_machine.go:36,131-148,310-320; special.go:12)
     const TileSrc src{&R, n, hard};
-#pragma unroll 1
-    for (int g = wave; g < kWords; g += kTileThreads / 64) {
-        const int q = g * 64 + lane;
-        const uint32_t b = q < n ? (uint32_t)R.b[q] : 0x100u;
-        bool rs = false, cl = false, cn = false, cnl = false, csp = false, cws = false, inv = false, nx = false;
-        const uint32_t lo = b | 0x20u;
-        if (b < 0x80u) {
-            rs = true;
-            cl = (lo - 'a') < 26u;
-            cn = (b - '0') < 10u;
-            csp = b == ' ';
-            cnl = b == '\n' || b == '\r';
-            cws = (b - 9u) < 5u && !cnl;
-        } else if (b < 0x100u) {
-            const uint32_t wd = byte_info(src, q, T.cls_stage1, T.cls_blocks);
-            const uint32_t c = wd & I_CLS;
-            rs = (wd & I_RUNE) != 0;
-            cl = rs && c == C_L;
-            cn = rs && c == C_N;
-            nx = cn;
-            cws = rs && c == C_WS;
-            inv = (wd & I_INVALID) != 0;
+    if (cls_thread) {
+        const uint32_t valid = c0 + 16 <= n ? 0xFFFFu : (c0 < n ? (1u << (n - c0)) - 1u : 0u);
+        uint32_t m_inv = 0, m_nx = 0;
+        uint32_t hi = ~m_rs & valid;  // bytes >= 0x80
+        while (hi) {
+            const int k = __builtin_ctz(hi);
+            hi &= hi - 1;
+            const uint32_t wd = byte_info(src, c0 + k, T.cls_stage1, T.cls_blocks);
+            if (wd & I_RUNE) {
+                const uint32_t c = wd & I_CLS, bit = 1u << k;
+                m_rs |= bit;
+                if (c == C_L) m_l |= bit;
+                else if (c == C_N) { m_n |= bit; m_nx |= bit; }
+                else if (c == C_WS) m_ws |= bit;
+                if (wd & I_INVALID) m_inv |= bit;
+            }
         }
-        const u64 m_rs = __ballot(rs), m_l = __ballot(cl), m_n = __ballot(cn), m_nl = __ballot(cnl), m_sp = __ballot(csp),
-                  m_ws = __ballot(cws), m_inv = __ballot(inv), m_nx = __ballot(nx), m_apos = __ballot(b == '\''),
-                  m_stmd = __ballot(lo == 's' || lo == 't' || lo == 'm' || lo == 'd'), m_r = __ballot(lo == 'r'),
-                  m_e = __ballot(lo == 'e'), m_v = __ballot(lo == 'v'), m_ll = __ballot(lo == 'l');
-        if (lane == 0) {
-            R.bm[B_RS][g] = m_rs; R.bm[B_L][g] = m_l; R.bm[B_N][g] = m_n; R.bm[B_NL][g] = m_nl; R.bm[B_SP][g] = m_sp;
-            R.bm[B_WS][g] = m_ws; R.bm[B_INV][g] = m_inv; R.bm[B_NX][g] = m_nx; R.bm[B_APOS][g] = m_apos;
-            R.bm[B_STMD][g] = m_stmd; R.bm[B_R][g] = m_r; R.bm[B_E][g] = m_e; R.bm[B_V][g] = m_v; R.bm[B_LL][g] = m_ll;
+        uint32_t ap = m_apos;
+        while (ap) {
+            const int q = c0 + __builtin_ctz(ap);
+            ap &= ap - 1;
+            const uint32_t b1 = (uint32_t)R.b[q + 1] | 0x20u, b2 = (uint32_t)R.b[q + 2] | 0x20u;  // zero padded past n
+            if (b1 == 's' || b1 == 't' || b1 == 'm' || b1 == 'd') atomicOr(&R.bm[B_CE2][(q + 2) >> 6], 1ull << ((q + 2) & 63));
+            if ((b1 == 'r' && b2 == 'e') || (b1 == 'v' && b2 == 'e') || (b1 == 'l' && b2 == 'l'))
+                atomicOr(&R.bm[B_CE3][(q + 3) >> 6], 1ull << ((q + 3) & 63));
         }
-        if (b == '<') {
+        uint32_t lt = m_lt;
+        while (lt) {
+            const int q = c0 + __builtin_ctz(lt);
+            lt &= lt - 1;
             int canon = 0;
             const int len = special_match(src, q, &canon);
             if (len) {
@@ -583,6 +610,16 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                 }
             }
         }
+        uint16_t* h;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_RS]); h[tid] = (uint16_t)m_rs;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_L]); h[tid] = (uint16_t)m_l;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_N]); h[tid] = (uint16_t)m_n;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_NL]); h[tid] = (uint16_t)m_nl;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_SP]); h[tid] = (uint16_t)m_sp;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_WS]); h[tid] = (uint16_t)m_ws;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_APOS]); h[tid] = (uint16_t)m_apos;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_INV]); h[tid] = (uint16_t)m_inv;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_NX]); h[tid] = (uint16_t)m_nx;
     }
     __syncthreads();
 
@@ -705,7 +742,8 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                     if (len < 4) { w0 &= (1u << (len * 8)) - 1u; w1 = 0; w2 = 0; }
                     else if (len < 8) { w1 = len == 4 ? 0u : (w1 & ((1u << ((len - 4) * 8)) - 1u)); w2 = 0; }
                     else if (len < 12) { w2 = len == 8 ? 0u : (w2 & ((1u << ((len - 8) * 8)) - 1u)); }
-                    id = vocab_lookup_short(T, w0, w1, w2, (uint32_t)len);
+                    if (A.flags & 0x400u) id = (int32_t)((w0 ^ w1 ^ w2) & 0xFFFFu);
+                    else id = vocab_lookup_short(T, w0, w1, w2, (uint32_t)len);
                 } else if (!inval && len <= kMaxTokenBytes) {
                     id = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)R.b[s + i]; }, (uint32_t)len);
                 }

@@ -11,7 +11,7 @@ d_text = torch.from_numpy(text).cuda(); d_off = torch.from_numpy(off.astype(np.i
 cap = text.size
 d_out = torch.empty(cap, dtype=torch.int32, device="cuda"); d_oo = torch.empty(n_docs + 1, dtype=torch.int64, device="cuda")
 ctx.set_profiling(True)
-for name, fl in [("full", 3), ("no-mergeloop", 3 | 0x100), ("no-vocab", 3 | 0x200)]:
+for name, fl in [("full", 3), ("no-mergeloop", 3 | 0x100), ("words-noprobe", 3 | 0x400), ("no-vocab", 3 | 0x200)]:
     for _ in range(3):
         rc, n = ctx.encode_batch_device(d_text.data_ptr(), text.size, d_off.data_ptr(), n_docs, fl, d_out.data_ptr(), cap, d_oo.data_ptr(), None)
     print(name, rc, n, ctx.last_timings())
