@@ -97,7 +97,7 @@ int upload_tables(l3_ctx* c) {
     T.bytepair = c->t_bytepair.as<uint32_t>();
     T.pair_buckets = c->t_pairs.as<PairBucket>();
     T.vocab_slots = c->t_vslots.as<VocabSlot>();
-    T.vocab_blob = c->t_vblob.as<uint8_t>();
+    T.vocab_blob = c->t_vblob.as<uint32_t>();
     T.special_id = c->t_special.as<int32_t>();
     T.pair_log2 = H.pair_log2;
     T.vocab_log2 = H.vocab_log2;

@@ -58,29 +58,35 @@ L3_HD int32_t vocab_lookup_short(const Tables& t, uint32_t w0, uint32_t w1, uint
     return r;
 }
 
-// Whole-string lookup.  `get(i)` returns byte i of the (already expanded) pre-token, 0 <= i < len.
-// Returns the token id or -1.
-template <class Get>
-L3_HD int32_t vocab_lookup(const Tables& t, Get get, uint32_t len) {
+// Whole-string lookup by words.  `getw(i)` returns little-endian word i of the (already expanded) pre-token,
+// 0 <= i < (len + 3) / 4, the last one zero padded.  Returns the token id or -1.
+template <class GetW>
+L3_HD int32_t vocab_lookup_words(const Tables& t, GetW getw, uint32_t len) {
     if (len == 0 || len > (uint32_t)kMaxTokenBytes) return -1;
-    if (len <= (uint32_t)kVocabInline) {
-        uint32_t w[3] = {0, 0, 0};
-        for (uint32_t i = 0; i < len; i++) w[i >> 2] |= get(i) << ((i & 3) * 8);
-        return vocab_lookup_short(t, w[0], w[1], w[2], len);
-    }
+    const uint32_t nw = (len + 3u) >> 2;
+    if (len <= (uint32_t)kVocabInline) return vocab_lookup_short(t, getw(0), nw > 1 ? getw(1) : 0u, nw > 2 ? getw(2) : 0u, len);
     StrHash h = strhash_init();
-    for (uint32_t i = 0; i < len; i++) strhash_add(h, get(i));
+    for (uint32_t i = 0; i < nw; i++) strhash_add(h, getw(i));
     uint32_t b[2];
     strhash_buckets(h, len, t.vocab_log2, &b[0], &b[1]);
     for (int k = 0; k < 4; k++) {
         const VocabSlot v = t.vocab_slots[2u * b[k >> 1] + (uint32_t)(k & 1)];
         if (v.w[3] == kVocabEmpty || (v.w[3] >> 17) != len || v.w[0] != h.h2) continue;
-        const uint8_t* blob = t.vocab_blob + v.w[1];
+        const uint32_t* blob = t.vocab_blob + v.w[1];
         bool eq = true;
-        for (uint32_t i = 0; i < len && eq; i++) eq = blob[i] == get(i);
+        for (uint32_t i = 0; i < nw && eq; i++) eq = blob[i] == getw(i);
         if (eq) return (int32_t)(v.w[3] & 0x1FFFFu);
     }
     return -1;
+}
+// Same with a byte source: `get(i)` returns byte i, 0 <= i < len.
+template <class Get>
+L3_HD int32_t vocab_lookup(const Tables& t, Get get, uint32_t len) {
+    return vocab_lookup_words(t, [&](uint32_t i) {
+        uint32_t w = 0;
+        for (uint32_t k = 0; k < 4u && 4u * i + k < len; k++) w |= get(4u * i + k) << (8u * k);
+        return w;
+    }, len);
 }
 
 // In-place greedy merge of the symbols at positions [s, e) of `sym` (id >= 0 live, -1 dead) with the

@@ -43,7 +43,8 @@ L3_HD void pair_hash2(uint64_t key, uint32_t log2_buckets, uint32_t* b1, uint32_
 
 // ---- vocabulary table: raw token bytes -> id, two-choice (cuckoo) hashing, 32-byte buckets of two slots --
 // slot: w[3] = id | len << 17 ; len <= 12: w[0..2] hold the bytes (little endian, zero padded);
-// len > 12: w[0] = second hash, w[1] = offset of the bytes in the blob, w[2] = 0.  empty: w[3] = 0xFFFFFFFF.
+// len > 12: w[0] = second hash, w[1] = WORD offset of the bytes in the blob (every entry starts on a
+// 4-byte boundary, its last word zero padded), w[2] = 0.  empty: w[3] = 0xFFFFFFFF.
 struct alignas(16) VocabSlot { uint32_t w[4]; };
 constexpr uint32_t kVocabEmpty = 0xFFFFFFFFu;
 constexpr int kVocabInline = 12;
@@ -51,22 +52,26 @@ L3_HD uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
 }
-// short strings (<= 12 bytes) hash their three little-endian words directly
+L3_HD uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+// short strings (<= 12 bytes) hash their three little-endian words directly (four multiplies in all)
 L3_HD void vocab_hash_short2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len, uint32_t log2_buckets, uint32_t* b1,
                              uint32_t* b2) {
     uint32_t x = w0 * 0x9E3779B1u;
-    x = (x ^ (x >> 15)) + w1 * 0x85EBCA6Bu;
-    x = (x ^ (x >> 13)) + w2 * 0xC2B2AE35u;
-    x ^= len * 0x27D4EB2Fu;
-    *b1 = mix32(x) >> (32 - log2_buckets);
-    *b2 = mix32(x * 0x2C1B3C6Du + 0x297A2D39u) >> (32 - log2_buckets);
+    x = (rotl32(x, 15) ^ w1) * 0x85EBCA6Bu;
+    x = rotl32(x, 13) ^ w2 ^ (len << 27);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
+    uint32_t z = x * 0x846CA68Bu;
+    z ^= z >> 16;
+    *b1 = x >> (32 - log2_buckets);
+    *b2 = z >> (32 - log2_buckets);
 }
-// longer strings: two running FNV-1a style hashes over the (expanded) pre-token bytes
+// longer strings: two running hashes over the little-endian words of the (expanded) pre-token, the last
+// word zero padded
 struct StrHash { uint32_t h1, h2; };
 L3_HD StrHash strhash_init() { return StrHash{2166136261u, 0x9747B28Cu}; }
-L3_HD void strhash_add(StrHash& h, uint32_t byte) {
-    h.h1 = (h.h1 ^ byte) * 16777619u;
-    h.h2 = (h.h2 + byte + 1u) * 0x85EBCA6Bu; h.h2 ^= h.h2 >> 15;
+L3_HD void strhash_add(StrHash& h, uint32_t word) {
+    h.h1 = (h.h1 ^ word) * 0x9E3779B1u; h.h1 ^= h.h1 >> 15;
+    h.h2 = (h.h2 + word) * 0x85EBCA6Bu; h.h2 ^= h.h2 >> 13;
 }
 L3_HD void strhash_buckets(const StrHash& h, uint32_t len, uint32_t log2_buckets, uint32_t* b1, uint32_t* b2) {
     *b1 = mix32(h.h1 ^ (len * 0x9E3779B1u)) >> (32 - log2_buckets);
@@ -86,7 +91,7 @@ struct Tables {
     const uint32_t* bytepair;     // [65536] prio of (byte a, byte b) indexed a<<8|b, kNoPrio if no rule
     const PairBucket* pair_buckets;  // [1 << pair_log2]
     const VocabSlot* vocab_slots; // [2 << vocab_log2]: bucket b = slots 2b, 2b+1
-    const uint8_t* vocab_blob;    // raw bytes of tokens longer than kVocabInline
+    const uint32_t* vocab_blob;   // raw bytes of tokens longer than kVocabInline, as zero-padded words
     const int32_t* special_id;    // [256] canonical special index -> token id (0 = not a token)
     uint32_t pair_log2;
     uint32_t vocab_log2;

@@ -56,7 +56,7 @@ void l3t_destroy(void* p) { delete (Handle*)p; }
 void l3t_stats(void* p, int64_t* out) {
     Handle* h = (Handle*)p;
     out[0] = h->H.n_tokens; out[1] = h->H.n_merges; out[2] = h->H.pair_log2; out[3] = h->H.vocab_log2;
-    out[4] = (int64_t)h->H.cls_blocks.size() / 64; out[5] = (int64_t)h->H.vocab_blob.size();
+    out[4] = (int64_t)h->H.cls_blocks.size() / 64; out[5] = (int64_t)h->H.vocab_blob.size() * 4;
 }
 
 int l3t_class_of(void* p, uint32_t cp) {

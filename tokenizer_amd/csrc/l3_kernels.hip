@@ -734,18 +734,26 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             if (e >= 0) {
                 inval = any_bit_in(R.bm[B_INV], s, e);
                 if (A.flags & 0x200u) id = 1;
-                else if (!inval && len <= kVocabInline) {
+                else if (!inval && len <= kMaxTokenBytes) {
+                    // little-endian words of the pre-token straight from the LDS image (unaligned start)
                     const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
-                    const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
                     const uint32_t sh = (uint32_t)(s & 3) * 8u;
-                    uint32_t w0 = __funnelshift_r(x0, x1, sh), w1 = __funnelshift_r(x1, x2, sh), w2 = __funnelshift_r(x2, x3, sh);
-                    if (len < 4) { w0 &= (1u << (len * 8)) - 1u; w1 = 0; w2 = 0; }
-                    else if (len < 8) { w1 = len == 4 ? 0u : (w1 & ((1u << ((len - 4) * 8)) - 1u)); w2 = 0; }
-                    else if (len < 12) { w2 = len == 8 ? 0u : (w2 & ((1u << ((len - 8) * 8)) - 1u)); }
-                    if (A.flags & 0x400u) id = (int32_t)((w0 ^ w1 ^ w2) & 0xFFFFu);
-                    else id = vocab_lookup_short(T, w0, w1, w2, (uint32_t)len);
-                } else if (!inval && len <= kMaxTokenBytes) {
-                    id = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)R.b[s + i]; }, (uint32_t)len);
+                    const uint32_t nw = ((uint32_t)len + 3u) >> 2;
+                    const uint32_t tail = (len & 3) ? (1u << ((len & 3) * 8)) - 1u : 0xFFFFFFFFu;
+                    if (len <= kVocabInline) {
+                        const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
+                        uint32_t w0 = __funnelshift_r(x0, x1, sh), w1 = __funnelshift_r(x1, x2, sh), w2 = __funnelshift_r(x2, x3, sh);
+                        if (nw == 1) { w0 &= tail; w1 = 0; w2 = 0; }
+                        else if (nw == 2) { w1 &= tail; w2 = 0; }
+                        else w2 &= tail;
+                        if (A.flags & 0x400u) id = (int32_t)((w0 ^ w1 ^ w2) & 0xFFFFu);
+                        else id = vocab_lookup_short(T, w0, w1, w2, (uint32_t)len);
+                    } else {
+                        id = vocab_lookup_words(T, [&](uint32_t i) {
+                            uint32_t x = __funnelshift_r(wp[i], wp[i + 1], sh);
+                            return i + 1 == nw ? x & tail : x;
+                        }, (uint32_t)len);
+                    }
                 }
             }
             if (id >= 0) item = id;

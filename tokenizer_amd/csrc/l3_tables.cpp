@@ -245,14 +245,18 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
             for (uint32_t k = 0; k < len; k++) slot.w[k >> 2] |= (uint32_t)(uint8_t)s[k] << ((k & 3) * 8);
         } else {
             StrHash h = strhash_init();
-            for (unsigned char c : s) strhash_add(h, c);
-            slot.w[0] = h.h2;
             slot.w[1] = (uint32_t)T.vocab_blob.size();
-            T.vocab_blob.insert(T.vocab_blob.end(), s.begin(), s.end());
+            for (uint32_t i = 0; i < len; i += 4) {
+                uint32_t w = 0;
+                for (uint32_t k = 0; k < 4 && i + k < len; k++) w |= (uint32_t)(uint8_t)s[i + k] << (8 * k);
+                strhash_add(h, w);
+                T.vocab_blob.push_back(w);
+            }
+            slot.w[0] = h.h2;
         }
         items.push_back(slot);
     }
-    while (T.vocab_blob.size() % 16) T.vocab_blob.push_back(0);
+    while (T.vocab_blob.size() % 4) T.vocab_blob.push_back(0);
     std::sort(items.begin(), items.end(), [](const VocabSlot& a, const VocabSlot& b) { return (a.w[3] & 0x1FFFFu) < (b.w[3] & 0x1FFFFu); });
     auto vbuckets = [&](const VocabSlot& v, uint32_t* b) {
         uint32_t len = v.w[3] >> 17;
@@ -260,7 +264,7 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
             vocab_hash_short2(v.w[0], v.w[1], v.w[2], len, T.vocab_log2, &b[0], &b[1]);
         } else {
             StrHash h = strhash_init();
-            for (uint32_t k = 0; k < len; k++) strhash_add(h, T.vocab_blob[v.w[1] + k]);
+            for (uint32_t k = 0; k < (len + 3) / 4; k++) strhash_add(h, T.vocab_blob[v.w[1] + k]);
             strhash_buckets(h, len, T.vocab_log2, &b[0], &b[1]);
         }
     };

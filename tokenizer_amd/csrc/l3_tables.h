@@ -21,7 +21,7 @@ struct HostTables {
     uint32_t pair_log2 = 0;
     std::vector<VocabSlot> vocab_slots;
     uint32_t vocab_log2 = 0;
-    std::vector<uint8_t> vocab_blob;
+    std::vector<uint32_t> vocab_blob;  // words
     int32_t special_id[256];
     // raw bytes of every token id (0..128255) for Decode (tokenizer.go:339-354)
     std::vector<uint8_t> tok_bytes;
