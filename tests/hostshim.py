@@ -32,6 +32,8 @@ class HostShim:
         L.l3t_vocab_lookup.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
         L.l3t_bpe.restype = C.c_int64
         L.l3t_bpe.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.l3t_bpe_rounds.restype = C.c_int64
+        L.l3t_bpe_rounds.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
         L.l3t_token_bytes.restype = C.c_int64
         L.l3t_token_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         vocab = open(os.path.join(DATA, "vocab_base64.txt"), "rb").read()
@@ -65,6 +67,14 @@ class HostShim:
         out = np.empty(cap, dtype=np.int32)
         n = self.lib.l3t_bpe(self.h, raw, len(raw), out.ctypes.data, cap)
         return out[:n].tolist()
+
+    def bpe_rounds(self, raw: bytes):
+        """Round-based merge (the slow kernel's algorithm, emulated sequentially).  Returns (ids, rounds)."""
+        cap = len(raw) + 1
+        out = np.empty(cap, dtype=np.int32)
+        nr = C.c_int64(0)
+        n = self.lib.l3t_bpe_rounds(self.h, raw, len(raw), out.ctypes.data, cap, C.byref(nr))
+        return out[:n].tolist(), nr.value
 
     def token_bytes(self, tid):
         buf = np.empty(160, dtype=np.uint8)

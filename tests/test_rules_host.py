@@ -125,3 +125,28 @@ def test_bpe_unreachable_tokens(shim, oracle):
     for tid in (100769, 100827, 101503, 101673, 103084):
         raw = shim.token_bytes(tid)
         assert shim.bpe(raw) == [tid] == oracle.bpe_raw(raw)
+
+
+def test_round_based_merge_is_exact(shim, oracle):
+    """The slow kernel's round algorithm (all local minima below theta per round) against the sequential
+    greedy merge of the oracle, with no whole-string shortcut: words, byte soup, runs, CJK, Cyrillic."""
+    rng = random.Random(17)
+    cases = [corpus.random_word(rng, lo=2, hi=60) for _ in range(20000)]
+    cases += [bytes(rng.choice(b"ab") for _ in range(rng.randint(2, 80))) for _ in range(4000)]
+    cases += [bytes(rng.choice(b"abcde ") for _ in range(rng.randint(2, 200))) for _ in range(3000)]
+    cases += [corpus.random_bytes_doc(rng, rng.randint(2, 120)) for _ in range(3000)]
+    cases += ["".join(chr(rng.randrange(0x4E00, 0x9FA5)) for _ in range(rng.randint(1, 300))).encode() for _ in range(300)]
+    cases += ["".join(chr(rng.randrange(0x410, 0x450)) for _ in range(rng.randint(1, 200))).encode() for _ in range(500)]
+    cases += [b"a" * k for k in range(2, 70)] + [b"ab" * 500, b"aab" * 300, b" " * 1000, b"\t" * 777, b"!" * 999, b"0" * 500]
+    cases += [("the quick brown fox jumps over the lazy dog " * 20).encode(), "文字".encode() * 400, ("ab" * 40 + "c") .encode() * 30]
+    total_rounds = total_merges = 0
+    for w in cases:
+        got, nr = shim.bpe_rounds(w)
+        exp = oracle.bpe_raw(w) if len(w) > 128 or shim.vocab_lookup(w) < 0 else None
+        if exp is None:  # the oracle would take the whole-string shortcut: compare with the plain merge loop
+            exp = shim.bpe(w) if shim.vocab_lookup(w) < 0 else None
+        if exp is not None:
+            assert got == exp, w
+            total_rounds += nr
+            total_merges += len(w) - len(got)
+    assert total_rounds < total_merges  # rounds really do batch several merges

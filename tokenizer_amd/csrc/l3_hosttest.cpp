@@ -130,6 +130,89 @@ int64_t l3t_bpe(void* hp, const uint8_t* bytes, int64_t n, int32_t* out, int64_t
     return k;
 }
 
+// Sequential emulation of the ROUND-BASED merge of the slow kernel (l3_kernels.hip merge_rounds): same set S,
+// same beta / theta rule, same compaction; lets the CPU suite fuzz the algorithm against the oracle.
+// Returns the number of tokens; *rounds receives the number of rounds it took.
+int64_t l3t_bpe_rounds(void* hp, const uint8_t* bytes, int64_t n0, int32_t* out, int64_t cap, int64_t* rounds) {
+    Handle* h = (Handle*)hp;
+    const Tables& T = h->T;
+    std::vector<int32_t> sa((size_t)n0), sb;
+    std::vector<uint32_t> pa((size_t)n0, kNoPrio), pb;
+    for (int64_t i = 0; i < n0; i++) sa[i] = T.byte_tok[bytes[i]];
+    for (int64_t i = 0; i + 1 < n0; i++) pa[i] = T.bytepair[((uint32_t)bytes[i] << 8) | bytes[i + 1]];
+    int64_t nr = 0;
+    size_t n = (size_t)n0;
+    for (;;) {
+        if (n < 2) break;
+        uint32_t r = kNoPrio;
+        for (size_t i = 0; i < n; i++) r = pa[i] < r ? pa[i] : r;
+        if (r == kNoPrio) break;
+        nr++;
+        std::vector<uint8_t> sel(n + 2, 0);
+        uint32_t run = 0;
+        for (size_t i = 0; i < n; i++) {
+            uint32_t p = pa[i];
+            if (p != r) {
+                run = 0;
+                if (p != kNoPrio) {
+                    uint32_t pl = i >= 1 ? pa[i - 1] : kNoPrio, pn = pa[i + 1];
+                    if (pl > p && pn >= p) sel[i] = 1;
+                }
+            } else {
+                if (!(run & 1u)) sel[i] = 1;
+                run++;
+            }
+        }
+        unsigned long long th = ~0ull;
+        for (size_t i = 0; i < n; i++) {
+            uint32_t p = pa[i];
+            if (p == kNoPrio) continue;
+            unsigned long long key = ((unsigned long long)p << 32) | i;
+            if (!sel[i]) {
+                bool covered = (i >= 1 && sel[i - 1] && pa[i - 1] <= p) || (sel[i + 1] && pa[i + 1] < p);
+                if (!covered && key < th) th = key;
+                continue;
+            }
+            uint32_t m = prio_merged_id(p), v = kNoPrio;
+            if (i >= 1) {
+                uint32_t lsym = (uint32_t)sa[i - 1];
+                if (i >= 2 && sel[i - 2] && pa[i - 2] <= p) lsym = prio_merged_id(pa[i - 2]);
+                v = pair_prio(T, lsym, m);
+            }
+            if (i + 2 < n) {
+                uint32_t rsym = (uint32_t)sa[i + 2];
+                if (sel[i + 2] && pa[i + 2] < p) rsym = prio_merged_id(pa[i + 2]);
+                uint32_t v2 = pair_prio(T, m, rsym);
+                v = v2 < v ? v2 : v;
+            }
+            unsigned long long beta = v == kNoPrio ? ~0ull : ((unsigned long long)v << 32);
+            if (beta < key + 1) beta = key + 1;
+            if (beta < th) th = beta;
+        }
+        sb.clear(); pb.clear();
+        std::vector<uint8_t> dirty;
+        for (size_t i = 0; i < n; i++) {
+            bool dead = i >= 1 && sel[i - 1] && ((((unsigned long long)pa[i - 1]) << 32) | (i - 1)) < th;
+            if (dead) continue;
+            bool applied = sel[i] && ((((unsigned long long)pa[i]) << 32) | i) < th;
+            sb.push_back(applied ? (int32_t)prio_merged_id(pa[i]) : sa[i]);
+            pb.push_back(pa[i]);
+            dirty.push_back(applied ? 1 : 0);
+        }
+        size_t n2 = sb.size();
+        for (size_t q = 0; q < n2; q++) {
+            bool d = dirty[q] || (q + 1 < n2 && dirty[q + 1]);
+            if (!d) continue;
+            pb[q] = q + 1 < n2 ? pair_prio(T, (uint32_t)sb[q], (uint32_t)sb[q + 1]) : kNoPrio;
+        }
+        sa.swap(sb); pa.swap(pb);
+        n = n2;
+    }
+    if (rounds) *rounds = nr;
+    for (size_t i = 0; i < n && (int64_t)i < cap; i++) out[i] = sa[i];
+    return (int64_t)n;
+}
+
 // Decode table access for tests: raw bytes of token id (tokenizer.go:339-354)
 int64_t l3t_token_bytes(void* hp, int32_t id, uint8_t* out, int64_t cap) {
     Handle* h = (Handle*)hp;

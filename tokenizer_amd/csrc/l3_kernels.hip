@@ -936,11 +936,21 @@ constexpr int32_t kIdMask = 0x1FFFF;
 constexpr int32_t kSelBit = 1 << 30;
 constexpr int32_t kDirtyBit = 1 << 29;
 
-// Exact round-based greedy merge of the n symbols in (sa, pa); (sb, pb) is the other buffer of the
-// pair.  Every round applies, left to right, the non-overlapping occurrences of the currently
-// smallest priority for as long as no merge creates a pair that out-ranks it (then the sequential
-// order of bpe.go:49-59 would leave this priority, so the round stops there).  Returns the buffer
-// that holds the result and the new n.
+// Exact round-based greedy merge of the n symbols in (sa, pa); (sb, pb) is the other buffer of the pair.
+//
+// The reference applies one merge at a time, always the pair with the smallest key = (rank, position)
+// (bpe.go:49-59, priority_queue.go:20-25).  A round here applies MANY of those steps at once:
+//   S     = an independent set of pairs that the sequential order would reach with unchanged operands if
+//           nothing new interfered: every strict local minimum of the key, plus, for the currently smallest
+//           rank r, the occurrences of r alternating from the left inside runs x x x ... (which overlap)
+//   beta  = for s in S: max(key(s) + 1, key of the best pair that merging s creates, probed with the
+//           neighbours s will see at its turn: products of adjacent lower-key members of S, else the
+//           present symbols).  Nothing with a key >= beta(s) may be applied blindly after s.
+//   theta = min(beta over S, keys of pairs outside S that no lower-key member of S overlaps)
+// Every member of S with key < theta is applied; by induction over the key order these are exactly the next
+// steps of the sequential algorithm (everything with a smaller key is applied, dead, or a new pair with
+// key >= theta), so the result is identical.  The pair with the smallest key always qualifies.
+// Returns the new n; sa/pa are left pointing at the buffers that hold the result.
 __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, int32_t*& sb, uint32_t*& pb, uint32_t n,
                                  uint32_t* tmp, unsigned long long* tmp64, Seg* segtmp) {
     const uint32_t tid = threadIdx.x;
@@ -949,7 +959,7 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
         const uint32_t chunk = (n + kSlowThreads - 1) / kSlowThreads;
         const uint32_t i0 = tid * chunk < n ? tid * chunk : n;
         const uint32_t i1 = i0 + chunk < n ? i0 + chunk : n;
-        // (a) smallest priority and where it first occurs
+        // (a) smallest key
         unsigned long long best = ~0ull;
         for (uint32_t i = i0; i < i1; i++) {
             unsigned long long v = ((unsigned long long)pa[i] << 32) | i;
@@ -959,26 +969,29 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
         const uint32_t r = (uint32_t)(best >> 32);
         if (r == kNoPrio) break;
         const uint32_t ipos = (uint32_t)best;
-        const int32_t m = (int32_t)prio_merged_id(r);
         const bool same = (sa[ipos] & kIdMask) == (sa[ipos + 1] & kIdMask);
         __syncthreads();
-        // (b) select occurrences; overlapping ones (x x x ...) alternate starting from the left
+        // (b) the set S
         {
             Seg sg; sg.cnt = 0; sg.open = 1;
             uint32_t first_break = n;
             for (uint32_t i = i0; i < i1; i++) {
-                bool cand = pa[i] == r;
+                const uint32_t p = pa[i];
                 int32_t v = sa[i] & kIdMask;
-                if (!cand) {
+                if (p != r) {
                     sg.cnt = 0; sg.open = 0;
                     if (first_break == n) first_break = i;
+                    if (p != kNoPrio) {  // strict local minimum of (rank, position); pa[n - 1] is kNoPrio
+                        const uint32_t pl = i >= 1 ? pa[i - 1] : kNoPrio, pn = pa[i + 1];
+                        if (pl > p && pn >= p) v |= kSelBit;
+                    }
                 } else {
                     if (!(sg.cnt & 1u)) v |= kSelBit;
                     sg.cnt++;
                 }
                 sa[i] = v;
             }
-            if (same) {  // chains can cross chunk borders only when both symbols are equal
+            if (same) {  // runs of r can cross chunk borders only when both symbols are equal
                 Seg carry = block_seg_escan(sg, segtmp);
                 if (carry.cnt & 1u) {
                     uint32_t lim = first_break < i1 ? first_break : i1;
@@ -987,32 +1000,48 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
             }
         }
         __syncthreads();
-        // (c) first selected merge after which the sequential order would leave priority r
-        unsigned long long vmin = ~0ull;
+        // (c) theta
+        unsigned long long th = ~0ull;
         for (uint32_t i = i0; i < i1; i++) {
-            if (!(sa[i] & kSelBit)) continue;
-            bool viol = false;
-            if (i >= 1) {
-                int32_t lp = (i >= 2 && (sa[i - 2] & kSelBit)) ? m : (sa[i - 1] & kIdMask);
-                viol = pair_prio(T, (uint32_t)lp, (uint32_t)m) < r;
+            const uint32_t p = pa[i];
+            if (p == kNoPrio) continue;
+            const unsigned long long key = ((unsigned long long)p << 32) | i;
+            if (!(sa[i] & kSelBit)) {
+                const bool covered = (i >= 1 && (sa[i - 1] & kSelBit) && pa[i - 1] <= p) || ((sa[i + 1] & kSelBit) && pa[i + 1] < p);
+                if (!covered) th = key < th ? key : th;
+                continue;
             }
-            if (!viol && i + 2 < n) viol = pair_prio(T, (uint32_t)m, (uint32_t)(sa[i + 2] & kIdMask)) < r;
-            if (viol) { vmin = i; break; }
+            const uint32_t m = prio_merged_id(p);
+            uint32_t v = kNoPrio;
+            if (i >= 1) {
+                uint32_t lsym = (uint32_t)(sa[i - 1] & kIdMask);
+                if (i >= 2 && (sa[i - 2] & kSelBit) && pa[i - 2] <= p) lsym = prio_merged_id(pa[i - 2]);
+                v = pair_prio(T, lsym, m);
+            }
+            if (i + 2 < n) {
+                uint32_t rsym = (uint32_t)(sa[i + 2] & kIdMask);
+                if ((sa[i + 2] & kSelBit) && pa[i + 2] < p) rsym = prio_merged_id(pa[i + 2]);
+                const uint32_t v2 = pair_prio(T, m, rsym);
+                v = v2 < v ? v2 : v;
+            }
+            unsigned long long beta = v == kNoPrio ? ~0ull : ((unsigned long long)v << 32);
+            if (beta < key + 1) beta = key + 1;
+            th = beta < th ? beta : th;
         }
-        vmin = block_min64(vmin, tmp64);
-        // (d) apply the selected merges up to vmin, compacting into the other buffer
+        th = block_min64(th, tmp64);
+        // (d) apply the members of S below theta, compacting into the other buffer
         uint32_t live = 0;
         for (uint32_t i = i0; i < i1; i++) {
-            bool dead = i >= 1 && (sa[i - 1] & kSelBit) && (unsigned long long)(i - 1) <= vmin;
+            const bool dead = i >= 1 && (sa[i - 1] & kSelBit) && (((unsigned long long)pa[i - 1] << 32) | (i - 1)) < th;
             live += dead ? 0u : 1u;
         }
         uint32_t n2;
         uint32_t j = block_escan(live, tmp, &n2);
         for (uint32_t i = i0; i < i1; i++) {
-            bool dead = i >= 1 && (sa[i - 1] & kSelBit) && (unsigned long long)(i - 1) <= vmin;
+            const bool dead = i >= 1 && (sa[i - 1] & kSelBit) && (((unsigned long long)pa[i - 1] << 32) | (i - 1)) < th;
             if (dead) continue;
-            bool applied = (sa[i] & kSelBit) && (unsigned long long)i <= vmin;
-            sb[j] = applied ? (m | kDirtyBit) : (sa[i] & kIdMask);
+            const bool applied = (sa[i] & kSelBit) && (((unsigned long long)pa[i] << 32) | i) < th;
+            sb[j] = applied ? (int32_t)(prio_merged_id(pa[i]) | (uint32_t)kDirtyBit) : (sa[i] & kIdMask);
             pb[j] = pa[i];
             j++;
         }
