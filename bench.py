@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=DOCS_PER_GPU, help="documents per GPU (default: the C2 config)")
-    ap.add_argument("--cpu-sample-docs", type=int, default=32768)
+    ap.add_argument("--cpu-sample-docs", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -144,16 +144,19 @@ def main():
             ns = min(args.cpu_sample_docs, n_docs)
             oracle = Oracle()
             s_text, s_off = text[:ns * DOC_BYTES], off[:ns + 1]
+            passes = 8
             c0 = time.perf_counter()
-            exp_tok, exp_off = oracle.encode_batch(s_text, s_off, True, True, threads=threads)
+            for _ in range(passes):  # one tokenizer, its pre-token caches persist as the reference's default cache does
+                exp_tok, exp_off = oracle.encode_batch(s_text, s_off, True, True, threads=threads)
             cdt = time.perf_counter() - c0
             got_off = d_out_off[:ns + 1].cpu().numpy().astype(np.uint64)
             got_tok = d_out[:int(got_off[-1])].cpu().numpy()
             parity = bool(np.array_equal(got_off, exp_off) and np.array_equal(got_tok, exp_tok))
-            result["cpu_baseline"] = {"value": exp_tok.size / cdt, "unit": "tokens/s", "cores": threads, "kind": "port",
-                                      "sample": "first %d documents (%d MiB) of the same C2 shard, document-per-thread "
-                                                "work queue, per-thread pre-token caches" % (ns, ns * DOC_BYTES >> 20),
-                                      "seconds": cdt, "input_gb_per_s": ns * DOC_BYTES / cdt / 1e9}
+            result["cpu_baseline"] = {"value": passes * exp_tok.size / cdt, "unit": "tokens/s", "cores": threads, "kind": "port",
+                                      "sample": "%d passes over the first %d documents (%d MiB) of the same C2 shard; C restatement "
+                                                "of the reference algorithm, document-per-thread work queue, per-thread "
+                                                "pre-token caches kept across passes" % (passes, ns, ns * DOC_BYTES >> 20),
+                                      "seconds": cdt, "input_gb_per_s": passes * ns * DOC_BYTES / cdt / 1e9}
             result["parity_vs_oracle_on_sample"] = parity
             if not parity:
                 result["error"] = "GPU output differs from the oracle on the CPU-baseline sample"
