@@ -138,6 +138,16 @@ def main():
                          "algorithmic_bytes_per_launch": b_alg, "kernel_avg_ms": kern[dom],
                          "pipeline_achieved": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBS},
         }
+        # HBM traffic of the dominant kernel: not measurable from inside this process; taken from the committed
+        # rocprofv3 PMC passes of this same command (profiles/*_pmc_hbm_summary.json, see profiles/README.md)
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_summary.json")))[-1]
+            kinfo = json.load(open(pm))["kernels"][dom + "_kernel"]
+            result["roofline"]["traffic"] = kinfo["hbm_bytes_per_launch_corrected"]
+            result["roofline"]["traffic_source"] = os.path.relpath(pm, ROOT)
+        except Exception:
+            pass
         if not args.no_cpu_baseline:
             from tests.oracle import Oracle
             threads = min(16, os.cpu_count() or 1)
