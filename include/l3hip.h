@@ -30,6 +30,8 @@ typedef struct l3_ctx l3_ctx;
 /* EncodeOptions{BOS, EOS} (tokenizer.go:107-112); nil options == L3_BOS|L3_EOS (tokenizer.go:218-220) */
 #define L3_BOS 1u
 #define L3_EOS 2u
+/* special-token names in the text are ordinary text (the bare pre-tokenizer, pretokenizer.Tokenize) */
+#define L3_NO_SPECIAL 4u
 
 /* llama3.New() (tokenizer.go:142-213): builds the tables from the contents of the reference's two
  * embedded data files (internal/vocabulary/embed.go:13-20: vocab_base64.txt, merges_binary.txt) and
@@ -56,10 +58,11 @@ int l3_encode_batch_device(l3_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes,
                            uint64_t n_docs, uint32_t flags, int32_t* d_out_tok, uint64_t out_cap,
                            uint64_t* d_out_off, uint64_t* n_tok, void* stream);
 
-/* Tokenizer.PreTokenize (tokenizer.go:490-504) + tokens.SplitBySpecialTokens (special.go:48-83) as
- * boundaries: kinds[i] = 1 if a pre-token starts at byte i, 2 if a special token starts there, else 0.
- * Host pointers; kinds has doc_off[n_docs] entries. */
-int l3_pretokenize_batch(l3_ctx* ctx, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs,
+/* Pre-token boundaries: kinds[i] = 1 if a pre-token starts at byte i, 2 if a special token starts there, else 0.
+ * flags = L3_NO_SPECIAL: Tokenizer.PreTokenize (tokenizer.go:490-506 -> pretokenizer.Tokenize), which knows no
+ * special tokens; flags = 0: the split Encode makes, tokens.SplitBySpecialTokens (special.go:48-83) first and the
+ * pre-tokenizer on the text between.  Host pointers; kinds has doc_off[n_docs] entries. */
+int l3_pretokenize_batch(l3_ctx* ctx, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                          uint8_t* kinds);
 
 /* Tokenizer.DecodeBytes (tokenizer.go:339-354) for a batch of id sequences: ids outside

@@ -1,0 +1,520 @@
+// llama3.hpp -- host-side mirror of the reference's Go API for the encode path, in C++ (the reference is
+// compiled Go; no Go toolchain exists in the authoring image, see INTEGRATION.md for the cgo stub).
+// Header-only; everything goes through the C ABI of include/l3hip.h, so this file is exactly what the Go
+// shim would be, with the same names, argument meanings and error behaviour:
+//
+//   llama3::New(opts...)                      llama3/tokenizer.go:142-213, options.go:17-74
+//   Tokenizer::Encode / EncodeBytes           tokenizer.go:217-271  (nil options = BOS and EOS)
+//   Tokenizer::AppendTokens                   tokenizer.go:276-330
+//   Tokenizer::Decode / DecodeBytes           tokenizer.go:333-354
+//   Tokenizer::GetSpecialTokenID              tokenizer.go:357-368  (ErrInvalidToken / ErrTokenNotFound)
+//   Tokenizer::VocabSize / PreTokenize        tokenizer.go:420-422,490-504
+//   Tokenizer::EncodeBatch                    new, additive: the batched hot path
+//   scanner::Tokenizer, scanner::New/NewWithOptions, Scanner::Scan/Token/Text/Err
+//                                             llama3/scanner/scanner.go:12-111,241-333 (chunking rules :124-181,337-478)
+//   Tokenizer::NewScanner / Process           llama3/scanner.go:67-102 (Process writes uint32 little-endian)
+//   EncodeStreams                             new, additive: many streams, the scanner's chunks, ONE batch call
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "l3hip.h"
+
+namespace llama3 {
+
+// ---- errors (llama3/errors.go) ------------------------------------------------------------------------
+enum class ErrKind { None, DataNotFound, InvalidToken, TokenNotFound, Device, Reader };
+struct Error {
+    ErrKind kind = ErrKind::None;
+    std::string op, detail;
+    explicit operator bool() const { return kind != ErrKind::None; }
+    std::string Message() const { return op + ": " + detail; }
+};
+
+struct EncodeOptions {  // tokenizer.go:107-112
+    bool BOS = true;
+    bool EOS = true;
+};
+
+// ---- options (llama3/options.go) ----------------------------------------------------------------------
+struct Config {
+    std::string vocabPath, mergesPath;  // WithDataFiles
+    int device = 0;                     // new: which GPU holds the tables
+};
+typedef void (*OptionFn)(Config&, const void*);
+struct Option {
+    std::string a, b;
+    int i = 0;
+    int which = 0;
+    void Apply(Config& c) const {
+        if (which == 1) { c.vocabPath = a; c.mergesPath = b; }
+        if (which == 2) c.device = i;
+    }
+};
+inline Option WithDataFiles(const std::string& vocabPath, const std::string& mergesPath) {
+    Option o; o.which = 1; o.a = vocabPath; o.b = mergesPath; return o;
+}
+inline Option WithDevice(int device) { Option o; o.which = 2; o.i = device; return o; }
+
+// ---- io: the two interfaces the streaming surface needs (Go's io.Reader / io.Writer) -------------------
+struct Reader {
+    // Reads up to n bytes into p.  Returns the byte count; *eof is set at end of input (possibly together with
+    // bytes); a negative return is a read error.
+    virtual int Read(uint8_t* p, int n, bool* eof) = 0;
+    virtual ~Reader() {}
+};
+struct Writer {
+    virtual bool Write(const uint8_t* p, size_t n) = 0;
+    virtual ~Writer() {}
+};
+struct BytesReader : Reader {  // bytes.NewReader
+    const uint8_t* d; size_t n, pos = 0;
+    BytesReader(const void* data, size_t len) : d((const uint8_t*)data), n(len) {}
+    int Read(uint8_t* p, int k, bool* eof) override {
+        if (pos >= n) { *eof = true; return 0; }  // like bytes.Reader: EOF comes on the read after the last byte
+        size_t m = n - pos < (size_t)k ? n - pos : (size_t)k;
+        memcpy(p, d + pos, m);
+        pos += m;
+        return (int)m;
+    }
+};
+
+namespace scanner {
+
+// llama3/scanner/scanner.go:12-15 -- the seam a tokenizer has to fill for the whole streaming surface
+struct Tokenizer {
+    virtual std::vector<int> Encode(const std::string& text, const EncodeOptions* opts) = 0;
+    virtual int GetSpecialTokenID(const std::string& token, Error* err) = 0;
+    virtual ~Tokenizer() {}
+};
+
+struct Options {  // scanner.go:55-85,93-101
+    int bufSize = 4096;
+    int maxBuffer = 1024 * 1024;
+    EncodeOptions enc{false, false};
+};
+
+// The reader / accumulate half of the reference scanner (scanner.go:124-181,281-311,337-478): yields the
+// successive chunks the reference would hand to Encode.  Kept separate from the encode call so that chunks of
+// many streams can be encoded by one batch call.
+class Chunker {
+  public:
+    Chunker(Reader* r, const Options& o) : r_(r), o_(o) {}
+    // Next chunk into *out.  Returns false when the input is exhausted and no chunk is left, or on a reader error;
+    // *last is set on the chunk after which the input is known to be at EOF.  A chunk is empty at the empty read
+    // at EOF, and (a quirk of the reference kept as is) when maxBuffer is smaller than one UTF-8 sequence: the
+    // reference's Scan then returns false without being finished (scanner.go:208-212,271-277).
+    bool Next(std::string* out, bool* last, Error* err) {
+        out->clear();
+        *last = false;
+        if (failed_) return false;
+        if (done_ && text_.empty()) return false;
+        for (;;) {
+            bool got_err = false;
+            readMoreData(&got_err);
+            if ((int)text_.size() >= o_.maxBuffer) { handleMaxBufferReached(); break; }
+            if (got_err) {
+                failed_ = true;
+                if (err) { err->kind = ErrKind::Reader; err->op = "scan"; err->detail = "read error at offset " + std::to_string(text_.size()); }
+                return false;
+            }
+            if (done_) break;
+            if (hasTokenizationBoundary()) break;
+        }
+        out->swap(text_);
+        text_.clear();
+        *last = done_;
+        return true;
+    }
+    bool Done() const { return done_ && text_.empty(); }
+
+  private:
+    void readMoreData(bool* got_err) {  // scanner.go:124-149
+        std::vector<uint8_t> buf((size_t)o_.bufSize);
+        bool eof = false;
+        int n = r_->Read(buf.data(), o_.bufSize, &eof);
+        if (n > 0) {
+            std::string toWrite;
+            if (!pending_.empty()) { toWrite.swap(pending_); pending_.clear(); }
+            toWrite.append((const char*)buf.data(), (size_t)n);
+            handleBufferLimit(&toWrite);
+            text_ += toWrite;
+        }
+        if (eof) {
+            done_ = true;
+            if (!pending_.empty()) { text_ += pending_; pending_.clear(); }
+            return;
+        }
+        if (n < 0) *got_err = true;
+    }
+    void handleBufferLimit(std::string* toWrite) {  // scanner.go:153-166
+        if ((int)(text_.size() + toWrite->size()) > o_.maxBuffer) {
+            int maxWrite = o_.maxBuffer - (int)text_.size();
+            if (maxWrite > 0 && maxWrite < (int)toWrite->size()) {
+                int upTo = findUTF8Boundary(*toWrite, maxWrite);
+                if (upTo < (int)toWrite->size()) {
+                    pending_ = toWrite->substr((size_t)upTo);
+                    toWrite->resize((size_t)upTo);
+                }
+            }
+        }
+    }
+    void handleMaxBufferReached() {  // scanner.go:169-181
+        if ((int)text_.size() == o_.maxBuffer && pending_.empty()) {
+            if (!text_.empty() && !isValidUTF8Ending(text_)) {
+                int splitAt = findLastCompleteUTF8(text_);
+                if (splitAt < (int)text_.size()) {
+                    pending_ = text_.substr((size_t)splitAt);
+                    text_.resize((size_t)splitAt);
+                }
+            }
+        }
+    }
+    bool hasTokenizationBoundary() const {  // scanner.go:337-367
+        if (text_.empty()) return false;
+        uint8_t last = (uint8_t)text_.back();
+        if (last == ' ' || last == '\n' || last == '\t' || last == '\r') return true;
+        if ((last & 0xC0) == 0x80) return false;
+        return (int)text_.size() > o_.bufSize / 2;
+    }
+    static bool isValidUTF8Ending(const std::string& b) {  // scanner.go:370-403
+        if (b.empty()) return true;
+        uint8_t last = (uint8_t)b.back();
+        if (last < 0x80) return true;
+        if ((last & 0xC0) == 0x80) return false;
+        int expected = 0;
+        if ((last & 0xE0) == 0xC0) expected = 2;
+        else if ((last & 0xF0) == 0xE0) expected = 3;
+        else if ((last & 0xF8) == 0xF0) expected = 4;
+        return expected <= 1;
+    }
+    static int findLastCompleteUTF8(const std::string& b) {  // scanner.go:406-438
+        int len = (int)b.size();
+        for (int i = len - 1; i >= 0 && i >= len - 4; i--) {
+            uint8_t c = (uint8_t)b[(size_t)i];
+            if (c < 0x80) return i + 1;
+            if ((c & 0xC0) != 0x80) {
+                int seq = 0;
+                if ((c & 0xE0) == 0xC0) seq = 2;
+                else if ((c & 0xF0) == 0xE0) seq = 3;
+                else if ((c & 0xF8) == 0xF0) seq = 4;
+                return i + seq <= len ? i + seq : i;
+            }
+        }
+        return len;
+    }
+    static int findUTF8Boundary(const std::string& d, int maxBytes) {  // scanner.go:443-478
+        int len = (int)d.size();
+        if (maxBytes >= len) return len;
+        for (int i = maxBytes; i > 0 && i > maxBytes - 4; i--) {
+            if (i >= len) continue;
+            uint8_t b = (uint8_t)d[(size_t)i];
+            if (b < 0x80 || (b & 0xC0) != 0x80) return i;
+        }
+        if (maxBytes < len && (((uint8_t)d[(size_t)maxBytes]) & 0xC0) == 0x80) {
+            for (int i = maxBytes - 1; i >= 0 && i >= maxBytes - 4; i--)
+                if ((((uint8_t)d[(size_t)i]) & 0xC0) != 0x80) return i;
+        }
+        return maxBytes;
+    }
+
+    Reader* r_;
+    Options o_;
+    std::string text_, pending_;
+    bool done_ = false, failed_ = false;
+};
+
+// scanner.go:24-29,241-333
+class Scanner {
+  public:
+    Scanner(Tokenizer* t, Reader* r, const Options& o = Options()) : t_(t), ch_(r, o), o_(o) {}
+    bool Scan() {
+        if (err_) return false;
+        if (idx_ < tokens_.size()) { idx_++; return true; }
+        if (finished_) return false;
+        tokens_.clear();
+        idx_ = 0;
+        std::string chunk;
+        bool last = false;
+        bool have = ch_.Next(&chunk, &last, &err_);
+        if (err_) return false;
+        if (!have) { finished_ = true; return false; }
+        if (chunk.empty() && !last) return false;  // nothing to tokenize, not at EOF: scanner.go:208-212,277
+        if (chunk.empty()) {  // empty input at EOF: scanner.go:184-205
+            finished_ = true;
+            Error e, e2;
+            if (o_.enc.BOS && !sentBOS_) { int id = t_->GetSpecialTokenID("<|begin_of_text|>", &e); if (!e) { tokens_.push_back(id); sentBOS_ = true; } }
+            if (o_.enc.EOS) { int id = t_->GetSpecialTokenID("<|end_of_text|>", &e2); if (!e2) tokens_.push_back(id); }
+            if (tokens_.empty()) return false;
+            idx_ = 1;
+            return true;
+        }
+        EncodeOptions co;  // scanner.go:214-224: BOS only on the first chunk, EOS handled at the end
+        co.BOS = o_.enc.BOS && !sentBOS_;
+        co.EOS = false;
+        if (co.BOS) sentBOS_ = true;
+        tokens_ = t_->Encode(chunk, &co);
+        if (last) {
+            finished_ = true;
+            if (o_.enc.EOS) { Error e; int id = t_->GetSpecialTokenID("<|end_of_text|>", &e); if (!e) tokens_.push_back(id); }
+        }
+        if (tokens_.empty()) return false;
+        idx_ = 1;
+        return true;
+    }
+    int Token() const { return idx_ > 0 && idx_ <= tokens_.size() ? tokens_[idx_ - 1] : 0; }
+    std::string Text() const { return std::string(); }  // the reference never assigns lastText (scanner.go:40,323-325)
+    Error Err() const { return err_; }
+
+  private:
+    Tokenizer* t_;
+    Chunker ch_;
+    Options o_;
+    std::vector<int> tokens_;
+    size_t idx_ = 0;
+    bool sentBOS_ = false, finished_ = false;
+    Error err_;
+};
+
+}  // namespace scanner
+
+// ---- the tokenizer ------------------------------------------------------------------------------------
+class Tokenizer : public scanner::Tokenizer {
+  public:
+    ~Tokenizer() override { if (ctx_) l3_destroy(ctx_); }
+    Tokenizer(const Tokenizer&) = delete;
+    Tokenizer& operator=(const Tokenizer&) = delete;
+
+    // Encode (tokenizer.go:217-265): cannot fail in the reference; a device failure yields an empty result and
+    // is reported by LastError().
+    std::vector<int> Encode(const std::string& text, const EncodeOptions* opts) override {
+        return EncodeBytes((const uint8_t*)text.data(), text.size(), opts);
+    }
+    std::vector<int> EncodeBytes(const uint8_t* data, size_t n, const EncodeOptions* opts) {
+        std::vector<int> out;
+        AppendBytes(&out, data, n, opts);
+        return out;
+    }
+    // AppendTokens (tokenizer.go:276-330): Encode(text) appended to dst
+    std::vector<int>& AppendTokens(std::vector<int>& dst, const std::string& text, const EncodeOptions* opts) {
+        AppendBytes(&dst, (const uint8_t*)text.data(), text.size(), opts);
+        return dst;
+    }
+    // The batched hot path: documents [off[i], off[i+1]) of `text` -> ids + per-document offsets.
+    Error EncodeBatch(const uint8_t* text, const std::vector<uint64_t>& off, const EncodeOptions* opts,
+                      std::vector<int32_t>* ids, std::vector<uint64_t>* id_off) {
+        Error e;
+        const uint64_t n_docs = off.size() - 1, n_bytes = off.back();
+        ids->resize((size_t)(n_bytes + 2 * n_docs + 64));
+        id_off->resize((size_t)n_docs + 1);
+        for (;;) {
+            uint64_t n = 0;
+            int rc = l3_encode_batch(ctx_, text, off.data(), n_docs, flagsOf(opts), ids->data(), ids->size(), id_off->data(), &n);
+            if (rc == L3_E_OUTPUT_CAP) { ids->resize((size_t)n); continue; }
+            if (rc != L3_OK) { e.kind = ErrKind::Device; e.op = "encode"; e.detail = l3_last_error(ctx_); last_ = e; ids->clear(); return e; }
+            ids->resize((size_t)n);
+            return e;
+        }
+    }
+    std::string Decode(const std::vector<int>& ids) { return DecodeBytes(ids); }  // tokenizer.go:333-337
+    std::string DecodeBytes(const std::vector<int>& ids) {                         // tokenizer.go:339-354
+        std::vector<int32_t> v(ids.size());
+        for (size_t i = 0; i < ids.size(); i++)
+            v[i] = ids[i] < 0 ? -1 : (int32_t)ids[i];  // out of range: skipped
+        uint64_t off[2] = {0, v.size()}, ooff[2], n = 0;
+        std::string out(v.size() * 8 + 64, '\0');
+        for (;;) {
+            int rc = l3_decode_batch(ctx_, v.data(), off, 1, (uint8_t*)&out[0], out.size(), ooff, &n);
+            if (rc == L3_E_OUTPUT_CAP) { out.resize((size_t)n); continue; }
+            if (rc != L3_OK) { last_.kind = ErrKind::Device; last_.op = "decode"; last_.detail = l3_last_error(ctx_); return std::string(); }
+            out.resize((size_t)n);
+            return out;
+        }
+    }
+    int GetSpecialTokenID(const std::string& token, Error* err) override {  // tokenizer.go:357-368
+        int32_t id = 0;
+        int rc = l3_special_token_id(ctx_, token.data(), token.size(), &id);
+        if (rc != L3_OK) {
+            if (err) {
+                const bool shaped = token.size() >= 4 && token.compare(0, 2, "<|") == 0 && token.compare(token.size() - 2, 2, "|>") == 0;
+                err->kind = shaped ? ErrKind::TokenNotFound : ErrKind::InvalidToken;
+                err->op = "get special token";
+                err->detail = token;
+            }
+            return 0;
+        }
+        return id;
+    }
+    int VocabSize() const { return l3_vocab_size(ctx_); }  // tokenizer.go:420-422
+    // PreTokenize (tokenizer.go:490-506): the pieces of pretokenizer.Tokenize(text) -- which knows no special
+    // tokens -- each in the byte-level alphabet of internal/encoding/encoding.go:26-79 (every byte one rune: printable
+    // bytes themselves, the other 68 as U+0100...).  As in Go, text passes through []rune first, so every byte
+    // that is not part of a valid UTF-8 sequence has become U+FFFD (EF BF BD) before the mapping.
+    std::vector<std::string> PreTokenize(const std::string& text) {
+        std::vector<std::string> out;
+        for (const std::string& piece : PreTokenizeRaw(text)) out.push_back(ByteLevel(piece));
+        return out;
+    }
+    // the same pieces before the byte-level mapping
+    std::vector<std::string> PreTokenizeRaw(const std::string& text) {
+        std::vector<std::string> out;
+        if (text.empty()) return out;
+        std::vector<uint8_t> kinds(text.size());
+        uint64_t off[2] = {0, text.size()};
+        if (l3_pretokenize_batch(ctx_, (const uint8_t*)text.data(), off, 1, L3_NO_SPECIAL, kinds.data()) != L3_OK) {
+            last_.kind = ErrKind::Device; last_.op = "pretokenize"; last_.detail = l3_last_error(ctx_);
+            return out;
+        }
+        std::string cur;
+        for (size_t i = 0; i < text.size();) {
+            if (i && kinds[i]) { out.push_back(cur); cur.clear(); }
+            int w = ValidSeqLen((const uint8_t*)text.data() + i, text.size() - i);
+            if (w) { cur.append(text, i, (size_t)w); i += (size_t)w; }
+            else { cur += "\xEF\xBF\xBD"; i++; }
+        }
+        out.push_back(cur);
+        return out;
+    }
+    // Length of the valid UTF-8 sequence at p (Go utf8.DecodeRune: shortest form, no surrogates, <= U+10FFFF), 0 if none
+    static int ValidSeqLen(const uint8_t* p, size_t n) {
+        const uint8_t c = p[0];
+        if (c < 0x80) return 1;
+        if (c < 0xC2 || c > 0xF4) return 0;
+        const int w = c < 0xE0 ? 2 : c < 0xF0 ? 3 : 4;
+        if ((size_t)w > n) return 0;
+        uint8_t lo = 0x80, hi = 0xBF;
+        if (c == 0xE0) lo = 0xA0; else if (c == 0xED) hi = 0x9F; else if (c == 0xF0) lo = 0x90; else if (c == 0xF4) hi = 0x8F;
+        if (p[1] < lo || p[1] > hi) return 0;
+        for (int k = 2; k < w; k++) if ((p[k] & 0xC0) != 0x80) return 0;
+        return w;
+    }
+    static std::string ByteLevel(const std::string& raw) {  // encoding.go:26-79, EncodeBytes
+        std::string out;
+        for (unsigned char b : raw) {
+            unsigned cp;
+            if ((b >= 0x21 && b <= 0x7E) || (b >= 0xA1 && b <= 0xAC) || b >= 0xAE) cp = b;
+            else cp = 256u + (b <= 0x20 ? b : b == 0x7F ? 33u : b <= 0xA0 ? 34u + (b - 0x80u) : 67u);  // the 68 others in byte order
+            if (cp < 0x80) out += (char)cp;
+            else { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+        }
+        return out;
+    }
+    // NewScanner (llama3/scanner.go:67-75)
+    scanner::Scanner NewScanner(Reader* r, const scanner::Options& o = scanner::Options()) { return scanner::Scanner(this, r, o); }
+    // Process (llama3/scanner.go:77-102): every token as a little-endian uint32; returns the token count or -1
+    long long Process(Reader* r, Writer* w, const scanner::Options& o = scanner::Options()) {
+        scanner::Scanner sc(this, r, o);
+        long long count = 0;
+        while (sc.Scan()) {
+            uint32_t v = (uint32_t)sc.Token();
+            uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)};
+            if (!w->Write(b, 4)) return -1;
+            count++;
+        }
+        return sc.Err() ? -1 : count;
+    }
+    Error LastError() const { return last_; }
+    l3_ctx* Handle() const { return ctx_; }
+
+  private:
+    friend std::unique_ptr<Tokenizer> New(const std::vector<Option>& opts, Error* err);
+    Tokenizer() {}
+    static uint32_t flagsOf(const EncodeOptions* o) {  // nil => BOS and EOS (tokenizer.go:218-220)
+        if (!o) return L3_BOS | L3_EOS;
+        return (o->BOS ? L3_BOS : 0u) | (o->EOS ? L3_EOS : 0u);
+    }
+    void AppendBytes(std::vector<int>* dst, const uint8_t* data, size_t n, const EncodeOptions* opts) {
+        std::vector<int32_t> ids;
+        std::vector<uint64_t> id_off, off{0, (uint64_t)n};
+        if (EncodeBatch(data, off, opts, &ids, &id_off)) return;
+        dst->insert(dst->end(), ids.begin(), ids.end());
+    }
+    l3_ctx* ctx_ = nullptr;
+    Error last_;
+};
+
+inline bool ReadFile(const std::string& path, std::string* out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[65536];
+    size_t n;
+    out->clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+    fclose(f);
+    return true;
+}
+
+// New (tokenizer.go:142-213).  The Go package embeds the two data files; a C++ build names them with
+// WithDataFiles (options.go) or the L3_DATA_DIR environment variable.
+inline std::unique_ptr<Tokenizer> New(const std::vector<Option>& opts, Error* err) {
+    Config c;
+    for (const Option& o : opts) o.Apply(c);
+    if (c.vocabPath.empty()) {
+        const char* d = getenv("L3_DATA_DIR");
+        std::string dir = d ? d : "tokenizer_amd/data";
+        c.vocabPath = dir + "/vocab_base64.txt";
+        c.mergesPath = dir + "/merges_binary.txt";
+    }
+    std::string vocab, merges;
+    if (!ReadFile(c.vocabPath, &vocab) || !ReadFile(c.mergesPath, &merges)) {
+        if (err) { err->kind = ErrKind::DataNotFound; err->op = "load vocabulary"; err->detail = c.vocabPath; }
+        return nullptr;
+    }
+    std::unique_ptr<Tokenizer> t(new Tokenizer());
+    int rc = l3_create(vocab.data(), vocab.size(), merges.data(), merges.size(), c.device, &t->ctx_);
+    if (rc != L3_OK) {
+        if (err) { err->kind = rc == L3_E_DATA ? ErrKind::DataNotFound : ErrKind::Device; err->op = "l3_create"; err->detail = l3_last_error(nullptr); }
+        return nullptr;
+    }
+    return t;
+}
+
+// Many streams at once: every stream is cut into the reference scanner's chunks, all chunks of
+// all streams are encoded by ONE batch call, BOS goes on a stream's first chunk and EOS after its last, so the
+// result per stream equals what Scanner yields for it.
+inline Error EncodeStreams(Tokenizer& t, const std::vector<Reader*>& readers, const scanner::Options& o,
+                           std::vector<std::vector<int>>* out) {
+    Error e;
+    std::string text;
+    std::vector<uint64_t> off{0};
+    std::vector<size_t> first_chunk(readers.size() + 1, 0);
+    std::vector<char> at_eof(readers.size(), 0);
+    for (size_t s = 0; s < readers.size(); s++) {
+        scanner::Chunker ch(readers[s], o);
+        std::string chunk;
+        bool last = false;
+        first_chunk[s] = off.size() - 1;
+        at_eof[s] = false;
+        while (ch.Next(&chunk, &last, &e)) {
+            if (chunk.empty() && !last) break;  // where a `for sc.Scan()` loop over the reference scanner stops
+            if (!chunk.empty()) { text += chunk; off.push_back(text.size()); }
+            if (last) { at_eof[s] = true; break; }
+        }
+        if (e) return e;
+    }
+    first_chunk[readers.size()] = off.size() - 1;
+    std::vector<int32_t> ids;
+    std::vector<uint64_t> id_off;
+    EncodeOptions none{false, false};
+    e = t.EncodeBatch((const uint8_t*)text.data(), off, &none, &ids, &id_off);
+    if (e) return e;
+    out->assign(readers.size(), std::vector<int>());
+    Error ig;
+    const int bos = t.GetSpecialTokenID("<|begin_of_text|>", &ig), eos = t.GetSpecialTokenID("<|end_of_text|>", &ig);
+    for (size_t s = 0; s < readers.size(); s++) {
+        std::vector<int>& v = (*out)[s];
+        if (o.enc.BOS && (first_chunk[s + 1] > first_chunk[s] || at_eof[s])) v.push_back(bos);
+        v.insert(v.end(), ids.begin() + (long)id_off[first_chunk[s]], ids.begin() + (long)id_off[first_chunk[s + 1]]);
+        if (o.enc.EOS && at_eof[s]) v.push_back(eos);
+    }
+    return e;
+}
+
+}  // namespace llama3

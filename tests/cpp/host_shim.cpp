@@ -1,0 +1,154 @@
+// host_shim.cpp -- C entry points over include/llama3.hpp (the C++ mirror of the reference's Go API) so that the
+// pytest suite can drive it through ctypes.  Test support only.
+#include <vector>
+
+#include "../../include/llama3.hpp"
+
+using namespace llama3;
+
+namespace {
+// scanner_test.go:458-489 controlledReader: hands out the data in reads of the given sizes, then in reads as large
+// as the caller allows; EOF arrives on the read after the last byte.  A negative size = a read error at that point
+// (scanner_test.go:427-433 errorReader).
+struct ControlledReader : Reader {
+    const uint8_t* d; size_t n, pos = 0;
+    const int* sizes; int n_sizes, k = 0;
+    ControlledReader(const uint8_t* data, size_t len, const int* s, int ns) : d(data), n(len), sizes(s), n_sizes(ns) {}
+    int Read(uint8_t* p, int cap, bool* eof) override {
+        if (k < n_sizes && sizes[k] < 0) { k++; return -1; }
+        if (pos >= n) { *eof = true; return 0; }
+        int want = k < n_sizes ? sizes[k] : cap;
+        k++;
+        if (want < 0) return -1;
+        if (want > cap) want = cap;
+        size_t m = n - pos < (size_t)want ? n - pos : (size_t)want;
+        memcpy(p, d + pos, m);
+        pos += m;
+        return (int)m;
+    }
+};
+struct VecWriter : Writer {
+    std::vector<uint8_t> v;
+    bool Write(const uint8_t* p, size_t n) override { v.insert(v.end(), p, p + n); return true; }
+};
+}  // namespace
+
+extern "C" {
+
+// chunk ends (cumulative byte offsets) the scanner would encode and whether the scanner knew it was at EOF (an empty
+// chunk can only come last: the empty read at EOF); returns the count, -1 on a reader error
+long long l3h_chunks(const uint8_t* data, long long n, const int* sizes, int n_sizes, int buf_size, int max_buffer,
+                     long long* ends, uint8_t* lasts, long long cap) {
+    ControlledReader r(data, (size_t)n, sizes, n_sizes);
+    scanner::Options o;
+    if (buf_size > 0) o.bufSize = buf_size;
+    if (max_buffer > 0) o.maxBuffer = max_buffer;
+    scanner::Chunker ch(&r, o);
+    std::string chunk;
+    bool last = false;
+    Error e;
+    long long k = 0, total = 0;
+    while (ch.Next(&chunk, &last, &e)) {
+        total += (long long)chunk.size();
+        if (k < cap) { ends[k] = total; lasts[k] = last; }
+        k++;
+        if (last) break;
+    }
+    return e ? -1 : k;
+}
+
+void* l3h_new(int device, const char* data_dir, int* err_kind) {
+    Error e;
+    std::vector<Option> opts{WithDevice(device)};
+    if (data_dir) opts.push_back(WithDataFiles(std::string(data_dir) + "/vocab_base64.txt", std::string(data_dir) + "/merges_binary.txt"));
+    std::unique_ptr<Tokenizer> t = New(opts, &e);
+    if (err_kind) *err_kind = (int)e.kind;
+    return t.release();
+}
+void l3h_free(void* h) { delete (Tokenizer*)h; }
+
+static long long copy_out(const std::vector<int>& v, int* out, long long cap) {
+    for (size_t i = 0; i < v.size() && (long long)i < cap; i++) out[i] = v[i];
+    return (long long)v.size();
+}
+// opts_mode: 0 = nil options, 1 = use bos/eos
+long long l3h_encode(void* h, const char* text, long long n, int opts_mode, int bos, int eos, int* out, long long cap) {
+    EncodeOptions o{bos != 0, eos != 0};
+    return copy_out(((Tokenizer*)h)->Encode(std::string(text, (size_t)n), opts_mode ? &o : nullptr), out, cap);
+}
+long long l3h_append(void* h, const int* dst, long long n_dst, const char* text, long long n, int bos, int eos, int* out, long long cap) {
+    EncodeOptions o{bos != 0, eos != 0};
+    std::vector<int> v(dst, dst + n_dst);
+    ((Tokenizer*)h)->AppendTokens(v, std::string(text, (size_t)n), &o);
+    return copy_out(v, out, cap);
+}
+long long l3h_decode(void* h, const int* ids, long long n, char* out, long long cap) {
+    std::string s = ((Tokenizer*)h)->Decode(std::vector<int>(ids, ids + n));
+    memcpy(out, s.data(), s.size() < (size_t)cap ? s.size() : (size_t)cap);
+    return (long long)s.size();
+}
+int l3h_special(void* h, const char* name, int* err_kind) {
+    Error e;
+    int id = ((Tokenizer*)h)->GetSpecialTokenID(name, &e);
+    *err_kind = (int)e.kind;
+    return id;
+}
+int l3h_vocab_size(void* h) { return ((Tokenizer*)h)->VocabSize(); }
+// pieces concatenated into buf with their cumulative ends; raw = before the byte-level mapping
+long long l3h_pretokenize(void* h, const char* text, long long n, int raw, uint8_t* buf, long long buf_cap, long long* ends,
+                          long long cap) {
+    Tokenizer* t = (Tokenizer*)h;
+    std::vector<std::string> p = raw ? t->PreTokenizeRaw(std::string(text, (size_t)n)) : t->PreTokenize(std::string(text, (size_t)n));
+    long long tot = 0;
+    for (size_t i = 0; i < p.size(); i++) {
+        if (tot + (long long)p[i].size() <= buf_cap) memcpy(buf + tot, p[i].data(), p[i].size());
+        tot += (long long)p[i].size();
+        if ((long long)i < cap) ends[i] = tot;
+    }
+    return (long long)p.size();
+}
+// Scanner over a controlled reader; returns the token count, -1 on a reader error
+long long l3h_scan(void* h, const uint8_t* data, long long n, const int* sizes, int n_sizes, int buf_size, int max_buffer,
+                   int bos, int eos, int* out, long long cap) {
+    ControlledReader r(data, (size_t)n, sizes, n_sizes);
+    scanner::Options o;
+    if (buf_size > 0) o.bufSize = buf_size;
+    if (max_buffer > 0) o.maxBuffer = max_buffer;
+    o.enc.BOS = bos != 0; o.enc.EOS = eos != 0;
+    scanner::Scanner sc = ((Tokenizer*)h)->NewScanner(&r, o);
+    long long k = 0;
+    while (sc.Scan()) { if (k < cap) out[k] = sc.Token(); k++; }
+    return sc.Err() ? -1 : k;
+}
+long long l3h_process(void* h, const uint8_t* data, long long n, int bos, int eos, uint8_t* out, long long cap) {
+    BytesReader r(data, (size_t)n);
+    VecWriter w;
+    scanner::Options o;
+    o.enc.BOS = bos != 0; o.enc.EOS = eos != 0;
+    long long cnt = ((Tokenizer*)h)->Process(&r, &w, o);
+    memcpy(out, w.v.data(), w.v.size() < (size_t)cap ? w.v.size() : (size_t)cap);
+    return cnt;
+}
+// many streams through one batch call; out = concatenated ids, out_off = n_streams + 1 offsets
+long long l3h_streams(void* h, const uint8_t* data, const long long* off, int n_streams, int buf_size, int bos, int eos,
+                      int* out, long long cap, long long* out_off) {
+    std::vector<BytesReader> rs;
+    rs.reserve((size_t)n_streams);
+    for (int i = 0; i < n_streams; i++) rs.emplace_back(data + off[i], (size_t)(off[i + 1] - off[i]));
+    std::vector<Reader*> ps;
+    for (auto& r : rs) ps.push_back(&r);
+    scanner::Options o;
+    if (buf_size > 0) o.bufSize = buf_size;
+    o.enc.BOS = bos != 0; o.enc.EOS = eos != 0;
+    std::vector<std::vector<int>> res;
+    if (EncodeStreams(*(Tokenizer*)h, ps, o, &res)) return -1;
+    long long k = 0;
+    out_off[0] = 0;
+    for (int i = 0; i < n_streams; i++) {
+        for (int v : res[(size_t)i]) { if (k < cap) out[k] = v; k++; }
+        out_off[i + 1] = k;
+    }
+    return k;
+}
+
+}  // extern "C"

@@ -123,6 +123,33 @@ def test_boundaries_fuzz(ctx, oracle):
         assert got == st and (k[got] - 1).tolist() == kd, (i, d)
 
 
+def test_boundaries_fuzz_bare_pretokenizer(ctx, oracle):
+    # L3_NO_SPECIAL: special-token names are ordinary text (Tokenizer.PreTokenize, tokenizer.go:490-506)
+    from tokenizer_amd import capi
+    rng = random.Random(101)
+    docs = [corpus.random_doc(rng) for _ in range(8000)] + [corpus.random_bytes_doc(rng, rng.randint(0, 40)) for _ in range(1000)]
+    docs += [b"<|eot_id|>", b"a<|begin_of_text|>b<|end_of_text|>", b"x" * 3000 + b"<|eot_id|>" + b"y" * 3000]
+    text, off = capi.pack_docs(docs)
+    kinds = ctx.pretokenize_batch(text, off, specials=False)
+    assert int(kinds.max()) <= 1
+    o = off.astype(np.int64)
+    for i, d in enumerate(docs):
+        got = np.nonzero(kinds[o[i]:o[i + 1]])[0].tolist()
+        assert got == oracle.pretokenize(d), (i, d)
+
+
+def test_unknown_flag_bits_are_rejected(ctx):
+    from tokenizer_amd import capi
+    import ctypes as C
+    text = np.frombuffer(b"abc", dtype=np.uint8)
+    off = np.array([0, 3], dtype=np.uint64)
+    out = np.empty(16, dtype=np.int32)
+    ooff = np.empty(2, dtype=np.uint64)
+    n = C.c_uint64(0)
+    rc = ctx.lib.l3_encode_batch(ctx.h, text.ctypes.data, off.ctypes.data, 1, 0x100, out.ctypes.data, 16, ooff.ctypes.data, C.byref(n))
+    assert rc == capi.L3_E_INVALID_ARG
+
+
 def test_encode_fuzz_small_docs(ctx, oracle):
     rng = random.Random(7)
     docs = [corpus.random_doc(rng) for _ in range(30000)]

@@ -21,6 +21,7 @@ L3_E_NO_DEVICE = -5
 L3_E_NOT_FOUND = -6
 L3_BOS = 1
 L3_EOS = 2
+L3_NO_SPECIAL = 4
 
 # every symbol include/l3hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
@@ -31,7 +32,7 @@ SYMBOLS = [
     ("l3_encode_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     ("l3_encode_batch_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P,
                                         C.POINTER(C.c_uint64), _P]),
-    ("l3_pretokenize_batch", C.c_int, [_P, _P, _P, C.c_uint64, _P]),
+    ("l3_pretokenize_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P]),
     ("l3_decode_batch", C.c_int, [_P, _P, _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     ("l3_special_token_id", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]),
     ("l3_vocab_size", C.c_int, [_P]),
@@ -146,12 +147,13 @@ class Context:
         o = o.astype(np.int64)
         return [tok[o[i]:o[i + 1]].tolist() for i in range(len(docs))]
 
-    def pretokenize_batch(self, text, doc_off):
+    def pretokenize_batch(self, text, doc_off, specials=True):
+        """kinds per byte: 1 pre-token start, 2 special-token start.  specials=False: the bare pre-tokenizer."""
         text = np.ascontiguousarray(text, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
         kinds = np.zeros(max(int(text.size), 1), dtype=np.uint8)
         rc = self.lib.l3_pretokenize_batch(self.h, text.ctypes.data, doc_off.ctypes.data, doc_off.size - 1,
-                                           kinds.ctypes.data)
+                                           0 if specials else L3_NO_SPECIAL, kinds.ctypes.data)
         if rc != L3_OK:
             raise self._err(rc)
         return kinds[:text.size]

@@ -280,6 +280,15 @@ void l3_destroy(l3_ctx* c) {
 
 const char* l3_last_error(const l3_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+// flags are L3_BOS | L3_EOS | L3_NO_SPECIAL (the measurement builds of tools/build_variant.sh accept more)
+static bool bad_flags(l3_ctx* c, uint32_t flags) {
+#ifndef L3_DEBUG_FLAGS
+    if (flags & ~(L3_BOS | L3_EOS | L3_NO_SPECIAL)) { c->err = "unknown bits in flags"; return true; }
+#endif
+    (void)c; (void)flags;
+    return false;
+}
+
 int l3_encode_batch_device(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off,
                            uint64_t n_docs, uint32_t flags, int32_t* d_out_tok, uint64_t out_cap,
                            uint64_t* d_out_off, uint64_t* n_tok, void* stream) {
@@ -289,6 +298,7 @@ int l3_encode_batch_device(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, c
         c->err = "null pointer argument";
         return L3_E_INVALID_ARG;
     }
+    if (bad_flags(c, flags)) return L3_E_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     EncodeArgs A{};
     A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = flags;
@@ -303,6 +313,7 @@ int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uin
                     int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok) {
     if (!c) return L3_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (bad_flags(c, flags)) return L3_E_INVALID_ARG;
     if (!doc_off || !out_off || !n_tok || (!out_tok && out_cap)) { c->err = "null pointer argument"; return L3_E_INVALID_ARG; }
     int rc = check_offsets_host(c, doc_off, n_docs);
     if (rc) return rc;
@@ -344,9 +355,11 @@ int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uin
     return L3_OK;
 }
 
-int l3_pretokenize_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint8_t* kinds) {
+int l3_pretokenize_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                         uint8_t* kinds) {
     if (!c) return L3_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (bad_flags(c, flags)) return L3_E_INVALID_ARG;
     if (!doc_off) { c->err = "null pointer argument"; return L3_E_INVALID_ARG; }
     int rc = check_offsets_host(c, doc_off, n_docs);
     if (rc) return rc;
@@ -363,7 +376,7 @@ int l3_pretokenize_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off
     HIPCHK(c, hipMemcpyAsync(c->s_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s));
     EncodeArgs A{};
     A.text = c->s_text.as<uint8_t>(); A.n_bytes = n_bytes; A.doc_off = c->s_off.as<uint64_t>(); A.n_docs = n_docs;
-    A.flags = 0; A.out_tok = c->s_out.as<int32_t>(); A.out_cap = 0;  // boundaries only: the scatter is skipped
+    A.flags = flags & L3_NO_SPECIAL; A.out_tok = c->s_out.as<int32_t>(); A.out_cap = 0;  // boundaries only: the scatter is skipped
     A.out_off = c->s_outoff.as<uint64_t>(); A.kinds = c->s_kinds.as<uint8_t>();
     uint64_t total = 0;
     rc = encode_core(c, A, s, &total, nullptr);

@@ -22,6 +22,7 @@ constexpr int kSlowLds = 3072;    // symbols of a slow pre-token merged in LDS; 
 // A stream item is a token id (>= 0) or the placeholder -2 - e of a deferred pre-token: e < kSlowBase
 // is an index into Workspace::miss_in / miss_res (short: merged one lane each by merge_kernel), e >= kSlowBase is
 // kSlowBase + an index into Workspace::slow (long / invalid UTF-8 / open-ended: slow_kernel).
+constexpr uint32_t kNoSpecial = 4;  // EncodeArgs::flags: special-token names are ordinary text (bare pre-tokenizer)
 constexpr int32_t kDead = -1;
 constexpr uint32_t kSlowBase = 1u << 30;
 
@@ -86,7 +87,7 @@ struct EncodeArgs {
     uint64_t n_bytes;
     const uint64_t* doc_off;  // device, n_docs + 1 ascending offsets, doc_off[0] = 0, doc_off[n_docs] = n_bytes
     uint64_t n_docs;
-    uint32_t flags;           // bit0 BOS, bit1 EOS
+    uint32_t flags;           // bit0 BOS, bit1 EOS, bit2 kNoSpecial
     int32_t* out_tok;         // device
     uint64_t out_cap;
     uint64_t* out_off;        // device, n_docs + 1

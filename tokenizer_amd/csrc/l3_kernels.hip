@@ -153,7 +153,7 @@ __device__ __forceinline__ void region_load(RegionLds& R, const uint8_t* text, u
 }
 
 // info words (class, rune start, validity) + special-token overlay.  dsb must be final; contains barriers.
-__device__ __forceinline__ void region_classify(RegionLds& R, const LdsSrc& src, const Tables& T) {
+__device__ __forceinline__ void region_classify(RegionLds& R, const LdsSrc& src, const Tables& T, bool specials) {
     const int c0 = threadIdx.x * kPer;
     const int n = src.n;
 #pragma unroll 1
@@ -167,7 +167,7 @@ __device__ __forceinline__ void region_classify(RegionLds& R, const LdsSrc& src,
 #pragma unroll 1
     for (int j = 0; j < kPer; j++) {
         int q = c0 + j;
-        if (q >= n || R.b[q] != '<') continue;
+        if (!specials || q >= n || R.b[q] != '<') continue;
         int canon = 0;
         int len = special_match(src, q, &canon);
         if (!len) continue;
@@ -481,6 +481,14 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
     return flags;
 }
 
+// measurement knobs of tools/phase_timing.py (skip the merge loop / the vocabulary probe): compiled in only for the
+// A/B variants built with -DL3_DEBUG_FLAGS, never in the shipped library
+#ifdef L3_DEBUG_FLAGS
+#define L3_DBG(flags, bit) ((flags) & (bit))
+#else
+#define L3_DBG(flags, bit) false
+#endif
+
 #ifndef L3_TILE_OCC
 #define L3_TILE_OCC 6
 #endif
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             if ((b1 == 'r' && b2 == 'e') || (b1 == 'v' && b2 == 'e') || (b1 == 'l' && b2 == 'l'))
                 atomicOr(&R.bm[B_CE3][(q + 3) >> 6], 1ull << ((q + 3) & 63));
         }
-        uint32_t lt = m_lt;
+        uint32_t lt = (A.flags & kNoSpecial) ? 0u : m_lt;
         while (lt) {
             const int q = c0 + __builtin_ctz(lt);
             lt &= lt - 1;
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             const int len = e - s;
             if (e >= 0) {
                 inval = any_bit_in(R.bm[B_INV], s, e);
-                if (A.flags & 0x200u) id = 1;
+                if (L3_DBG(A.flags, 0x200u)) id = 1;
                 else if (!inval && len <= kMaxTokenBytes) {
                     // little-endian words of the pre-token straight from the LDS image (unaligned start)
                     const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
@@ -746,7 +754,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                         if (nw == 1) { w0 &= tail; w1 = 0; w2 = 0; }
                         else if (nw == 2) { w1 &= tail; w2 = 0; }
                         else w2 &= tail;
-                        if (A.flags & 0x400u) id = (int32_t)((w0 ^ w1 ^ w2) & 0xFFFFu);
+                        if (L3_DBG(A.flags, 0x400u)) id = (int32_t)((w0 ^ w1 ^ w2) & 0xFFFFu);
                         else id = vocab_lookup_short(T, w0, w1, w2, (uint32_t)len);
                     } else {
                         id = vocab_lookup_words(T, [&](uint32_t i) {
@@ -892,7 +900,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
                     for (int j = 0; j < 8; j++)
                         if (i + j < (int)len) { sym[s + i + j] = byte_tok[bb[j]]; pr[s + i + j] = pp[j]; }
                 }
-                if (!(A.flags & 0x100u)) merge_span(T, sym, pr, s, e);
+                if (!L3_DBG(A.flags, 0x100u)) merge_span(T, sym, pr, s, e);
                 n_out = 0;
                 for (int i = s; i < e; i++) n_out += sym[i] >= 0 ? 1u : 0u;
             }
@@ -1110,7 +1118,7 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
                 region_load(R, A.text, g_lo, n);
                 __syncthreads();
                 LdsSrc src{&R, n, hard};
-                region_classify(R, src, T);
+                region_classify(R, src, T, !(A.flags & kNoSpecial));
                 const int c0 = tid * kPer;
                 int found = n;
                 for (int j = 0; j < kPer; j++) {

@@ -1,4 +1,6 @@
-"""Timing experiment: tile-kernel time with phases disabled through debug flag bits (results are then wrong)."""
+"""Timing experiment: tile-kernel time with phases disabled through debug flag bits (results are then wrong).
+Needs a library built with the knobs: tools/build_variant.sh dbg "-DL3_DEBUG_FLAGS", then
+L3HIP_LIB=tokenizer_amd/lib/variants/libl3hip_dbg.so python tools/phase_timing.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
