@@ -180,14 +180,17 @@ def test_empty_inputs(ctx, oracle):
     check_batch(ctx, oracle, [b""] * 5000 + [b"x"] + [b""] * 5000, True, True, "many empties")
 
 
+BORDERS = (2048, 3840, 4096, 7680, 8192)
+
+
 def test_tile_borders(ctx, oracle):
-    # documents and pre-tokens straddling 4 KiB tile borders in every phase
+    # documents and pre-tokens straddling tile borders (tiles are 3,840 B; earlier builds used 2 and 4 KiB) in every phase
     rng = random.Random(10)
     for shift in range(0, 70, 3):
         docs = [b"x" * shift] + [corpus.random_doc(rng, max_pieces=40) for _ in range(400)]
         check_batch(ctx, oracle, docs, True, True, "shift %d" % shift)
     base = (b"The quick brown fox don't jump over 12345 lazy dogs!!\n\n  " * 200)
-    for cut in (4090, 4095, 4096, 4097, 4100, 8191, 8192, 8193):
+    for cut in [b + d for b in BORDERS for d in (-6, -1, 0, 1, 4)]:
         check_batch(ctx, oracle, [base[:cut], base[cut:]], True, True, "cut %d" % cut)
     check_batch(ctx, oracle, [base], True, True, "one 11 KB document")
 
@@ -197,10 +200,24 @@ def test_long_runs(ctx, oracle):
     docs = [b" " * n, b"\t" * n, b"\n \n " * (n // 4), b"0123456789" * (n // 10), b"a" * n, b"'s" * (n // 2),
             b"ab" * 3000, b"!" * 7000 + b"\n" * 300, ("٣".encode() * 5000), b"12" + "٣".encode() * 4101 + b"7" * 4099,
             b"\xff" * 5000, "中".encode() * 3000, ("文字" * 2500).encode(), b"x" * 100 + b" " * 9000 + b"y",
-            b"word " * 4000, b"a" * 64, b"a" * 65, b"a" * 191, b"a" * 192, b"a" * 193, b"a" * 4096, b"a" * 4097]
+            b"word " * 4000, b"a" * 64, b"a" * 65, b"a" * 191, b"a" * 192, b"a" * 193, b"a" * 4096, b"a" * 4097,
+            b"a" * 3839, b"a" * 3840, b"a" * 3841, b"7" * 3840, b"7" * 3841, b"7" * 3842, b"x" + b"7" * 7700]
     for i, d in enumerate(docs):
         check_batch(ctx, oracle, [d], True, True, "long run %d" % i)
     check_batch(ctx, oracle, docs, True, True, "long runs as one batch")
+
+
+def test_more_deferred_pretokens_than_a_tile_remembers(ctx, oracle):
+    # > 1,024 short and > 256 slow deferred pre-tokens inside one 3,840-byte tile (the tile kernel's LDS lists overflow)
+    rng = random.Random(5)
+    cands = [b" " + bytes([a, b]) for a in b"qxzjkvw" for b in b"qxzjkvw"]
+    multi = [c for c in cands if len(oracle.encode(c, False, False)) > 1]
+    assert len(multi) >= 8
+    short = b"".join(rng.choice(multi) for _ in range(8000))
+    slow = b"".join(b" " + bytes([rng.choice(b"abc"), 0xFF]) for _ in range(6000))   # invalid UTF-8 in every pre-token
+    check_batch(ctx, oracle, [short], True, True, "dense short misses")
+    check_batch(ctx, oracle, [slow], True, True, "dense slow pre-tokens")
+    check_batch(ctx, oracle, [short[:5000], slow[:7000], short[5000:] + slow[7000:]], True, False, "both")
 
 
 def test_special_tokens(ctx, oracle):
@@ -212,8 +229,9 @@ def test_special_tokens(ctx, oracle):
     docs.append(b" ".join(names))
     docs += names
     # specials straddling tile borders
-    for k in range(4060, 4100):
-        docs.append(b"a" * k + b"<|begin_of_text|>tail")
+    for b in BORDERS[:3]:
+        for k in range(b - 36, b + 4):
+            docs.append(b"a" * k + b"<|begin_of_text|>tail")
     check_batch(ctx, oracle, docs, True, True, "special tokens")
     check_batch(ctx, oracle, docs, False, False, "special tokens no BOS/EOS")
 

@@ -8,10 +8,15 @@
 namespace l3 {
 
 // ---- geometry of the tile kernel -----------------------------------------------------------------
-constexpr int kTile = 2048;       // bytes of text owned by one workgroup
+#ifndef L3_TILE_BYTES
+#define L3_TILE_BYTES 3840
+#endif
+constexpr int kTile = L3_TILE_BYTES;  // bytes of text owned by one workgroup
 constexpr int kBack = 64;         // look-behind halo (special token 30 B + 4 runes 16 B + slack)
 constexpr int kFwd = 192;         // look-ahead halo
-constexpr int kRegion = kBack + kTile + kFwd;
+constexpr int kRegion = kBack + kTile + kFwd;  // 4096: one 64-bit mask word per lane of a wave, 16 bytes per thread
+constexpr int kSBack = 64;        // the slow kernel's end-finding window (its own LDS image, info word per byte)
+constexpr int kSRegion = 2304;
 constexpr int kEvalSlack = 36;    // positions closer than this to a soft region end cannot be decided
 constexpr int kLaneMax = 64;      // longest pre-token (bytes) merged by a single lane in the tile kernel
 constexpr int kTileCap = kTile;  // stream items one tile can emit: one per pre-token that starts in it

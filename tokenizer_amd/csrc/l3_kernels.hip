@@ -27,10 +27,10 @@ namespace l3 {
 
 namespace {
 
-constexpr int kPer = kRegion / kTileThreads;  // consecutive region positions owned by one thread
-static_assert(kPer * kTileThreads == kRegion, "region must split evenly over the workgroup");
+constexpr int kPer = kSRegion / kTileThreads;  // consecutive region positions owned by one thread
+static_assert(kPer * kTileThreads == kSRegion, "region must split evenly over the workgroup");
 static_assert(kPer <= 32, "per-thread masks are 32 bit");
-constexpr int kBitWords = kRegion / 32 + 2;
+constexpr int kBitWords = kSRegion / 32 + 2;
 constexpr uint32_t I_DOFF_SHIFT = 12;  // bits 12..13 of an info word: offset inside a digit run, mod 3
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -108,12 +108,11 @@ __device__ __forceinline__ Seg block_seg_escan(Seg v, Seg* tmp) {
 
 // ---- the LDS image of one region of text --------------------------------------------------------
 struct RegionLds {
-    uint8_t b[kRegion + 16];     // raw bytes (16-byte aligned for vector stores)
-    uint32_t a[kRegion + 8];     // info word per byte; later: token id / kDead / kSlowMark / kMissMark
-    uint32_t p[kRegion + 8];     // special-token id; later: pair priority / deferred length
+    uint8_t b[kSRegion + 16];     // raw bytes (16-byte aligned for vector stores)
+    uint32_t a[kSRegion + 8];     // info word per byte; later: token id / kDead / kSlowMark / kMissMark
+    uint32_t p[kSRegion + 8];     // special-token id; later: pair priority / deferred length
     uint32_t dsb[kBitWords];     // document-start bits
     uint32_t stb[kBitWords];     // pre-token-start bits
-    uint16_t list[kTile];        // compacted local start offsets (pre-tokens, then merge candidates)
 };
 enum { V_NPRE = 0, V_FIRST, V_ELAST, V_NEED, V_FB, V_SLOW0, V_NMISS, V_END, V_COUNT = 16 };
 
@@ -147,7 +146,7 @@ __device__ __forceinline__ void region_load(RegionLds& R, const uint8_t* text, u
             *reinterpret_cast<uint4*>(&R.b[o]) = *reinterpret_cast<const uint4*>(src + o);
         } else {
             for (int k = 0; k < 16; k++)
-                if (o + k < kRegion + 16) R.b[o + k] = (o + k < n) ? src[o + k] : (uint8_t)0;
+                if (o + k < kSRegion + 16) R.b[o + k] = (o + k < n) ? src[o + k] : (uint8_t)0;
         }
     }
 }
@@ -160,9 +159,9 @@ __device__ __forceinline__ void region_classify(RegionLds& R, const LdsSrc& src,
     for (int j = 0; j < kPer; j++) {
         int q = c0 + j;
         if (q < n) R.a[q] = byte_info(src, q, T.cls_stage1, T.cls_blocks);
-        else if (q < kRegion + 8) R.a[q] = I_SEG | I_RUNE;
+        else if (q < kSRegion + 8) R.a[q] = I_SEG | I_RUNE;
     }
-    if (threadIdx.x < 8) R.a[kRegion + threadIdx.x] = I_SEG | I_RUNE;
+    if (threadIdx.x < 8) R.a[kSRegion + threadIdx.x] = I_SEG | I_RUNE;
     __syncthreads();
 #pragma unroll 1
     for (int j = 0; j < kPer; j++) {
@@ -264,16 +263,19 @@ __global__ void docs_kernel(Workspace W, EncodeArgs A, uint64_t n_tiles) {
 constexpr int kWords = kRegion / 64;
 static_assert(kWords * 64 == kRegion && kWords <= 64, "one wave must hold one mask word per lane");
 typedef unsigned long long u64;
-enum { B_RS = 0, B_L, B_N, B_NL, B_SP, B_WS, B_INV, B_APOS, B_NX, B_CE2, B_CE3,
-       B_DS, B_SPS, B_SPB, B_SPE, B_ST, B_CONTN, B_COUNT };
+// rows from B_LIVE on are dead once the start bits exist; the lookup phase reuses them as its item staging array
+enum { B_ST = 0, B_SPS, B_INV, B_DS, B_LIVE, B_RS = B_LIVE, B_L, B_N, B_NL, B_SP, B_WS, B_APOS, B_NX, B_CE2, B_CE3,
+       B_SPB, B_SPE, B_CONTN, B_COUNT };
 
+constexpr int kResCap = (B_COUNT - B_LIVE) * (kWords + 2) * 2;  // stream items staged in LDS (the rest goes straight to HBM)
 struct TileLds {
     uint8_t b[kRegion + 16];
     u64 bm[B_COUNT][kWords + 2];
-    int32_t res[kTile];        // stream item of every own pre-token
     uint16_t list[kTile];      // compacted own pre-token starts (region-local offsets)
     uint16_t wpre[kWords + 1]; // own pre-token starts before each mask word
 };
+constexpr int kListPer = 16;
+static_assert(kListPer * kTileThreads >= kTile && 64 % kListPer == 0 && kBack % kListPer == 0, "list compaction geometry");
 enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NMISS, TV_NSLOW, TV_MISS0, TV_SLOW0, TV_COUNT = 8 };
 
 struct TileSrc {  // byte source over the tile's LDS image, LOCAL coordinates [0, n)
@@ -699,20 +701,21 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     const uint32_t n_pre = (uint32_t)vars[TV_NPRE];
     const u64* ST = R.bm[B_ST];
 
-    // -- compacted list of own pre-token starts (8 byte positions per thread)
+    // -- compacted list of own pre-token starts (kListPer byte positions per thread; own_lo is 0 or kBack, so a
+    //    thread's positions never straddle a 64-bit mask word)
     {
-        const int pos = own_lo + tid * (kTile / kTileThreads);
+        const int pos = own_lo + tid * kListPer;
         if (pos < own_hi) {
             const int wd = pos >> 6, sh = pos & 63;
             const u64 word = ST[wd];
             u64 ownw = word;
             if (own_lo > wd * 64) ownw &= ~0ull << (own_lo - wd * 64);
-            uint32_t bits = (uint32_t)(word >> sh) & ((1u << (kTile / kTileThreads)) - 1u);
-            if (own_hi - pos < kTile / kTileThreads) bits &= (1u << (own_hi - pos)) - 1u;
+            uint32_t bits = (uint32_t)(word >> sh) & ((1u << kListPer) - 1u);
+            if (own_hi - pos < kListPer) bits &= (1u << (own_hi - pos)) - 1u;
             uint32_t base = R.wpre[wd] + (uint32_t)__popcll(ownw & ((1ull << sh) - 1ull));
             if (A.kinds) {
                 const u64 sps = R.bm[B_SPS][wd] >> sh;
-                for (int j = 0; j < kTile / kTileThreads && pos + j < own_hi; j++)
+                for (int j = 0; j < kListPer && pos + j < own_hi; j++)
                     A.kinds[g_lo + pos + j] = (bits >> j) & 1u ? (((sps >> j) & 1ull) ? 2 : 1) : 0;
             }
             while (bits) {
@@ -724,6 +727,8 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     }
     __syncthreads();
 
+    int32_t* res = reinterpret_cast<int32_t*>(&R.bm[B_LIVE][0]);
+    int32_t* out0 = W.stream + tile * (uint64_t)kTileCap;
     // -- per pre-token: special id / whole-string vocabulary probe (bpe.go:27-33) / defer.  One stream item each.
 #pragma unroll 1
     for (uint32_t k = tid; k < n_pre; k += kTileThreads) {
@@ -768,7 +773,9 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             else if (e >= 0 && !inval && len <= kLaneMax) item = -2 - (int32_t)atomicAdd(&vars[TV_NMISS], 1);  // local ordinal
             else item = -2 - (int32_t)(kSlowBase + (uint32_t)atomicAdd(&vars[TV_NSLOW], 1));
         }
-        R.res[k] = item;
+        // deferred: the local ordinal for now, replaced below by the global entry index.  Staged in LDS (the bitmap
+        // rows that are dead by now); text of one- and two-byte pre-tokens can exceed it and goes straight to HBM
+        if (k < (uint32_t)kResCap) res[k] = item; else out0[k] = item;
     }
     __syncthreads();
     const uint32_t shard = (uint32_t)(tile % kMissShards);
@@ -786,9 +793,51 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     {
         const uint32_t m0 = (uint32_t)vars[TV_MISS0], s0 = (uint32_t)vars[TV_SLOW0];
         int32_t* out = W.stream + tile * (uint64_t)kTileCap;
+        // Staged items first, then (rare) those past the staging array, which every thread re-reads from its own
+        // stores.  Keep the two loops written out like this: variants of this pass that used a shared lambda, or one
+        // loop selecting between res[k] and out[k], compiled to code that ran the whole kernel 2x slower on C2.
+        const uint32_t staged = n_pre < (uint32_t)kResCap ? n_pre : (uint32_t)kResCap;
 #pragma unroll 1
-        for (uint32_t k = tid; k < n_pre; k += kTileThreads) {
-            int32_t item = R.res[k];
+        for (uint32_t k = tid; k < staged; k += kTileThreads) {
+            int32_t item = res[k];
+            if (item < -1) {  // deferred: global entry index, entry record
+                uint32_t ord = (uint32_t)(-2 - item);
+                const bool slow = ord >= kSlowBase;
+                if (slow) ord -= kSlowBase;
+                const int s = R.list[k];
+                int e = find_next_bit64(ST, s + 1, eval_hi);
+                if (e < 0 && hard) e = n;
+                uint64_t ei;
+                if (slow) {
+                    ei = (uint64_t)s0 + ord;
+                    if (ei < W.slow_cap) {
+                        SlowEntry se;
+                        se.start = g_lo + (uint64_t)s;
+                        se.scan_from = g_lo + (uint64_t)eval_hi;
+                        se.len = e < 0 ? 0u : (uint32_t)(e - s);
+                        se.tile = (uint32_t)tile;
+                        se.count = 0; se.pad = 0; se.pool_off = 0;
+                        W.slow[ei] = se;
+                    }
+                    ei += kSlowBase;
+                } else {
+                    const uint64_t li = (uint64_t)m0 + ord;
+                    ei = shard * W.miss_shard_cap + li;
+                    if (li < W.miss_shard_cap) {
+                        MissIn mi;
+                        mi.start = g_lo + (uint64_t)s;
+                        mi.tile = (uint32_t)tile;
+                        mi.len = (uint32_t)(e - s);
+                        W.miss_in[ei] = mi;
+                    }
+                }
+                item = -2 - (int32_t)(uint32_t)ei;
+            }
+            out[k] = item;
+        }
+#pragma unroll 1
+        for (uint32_t k = staged + tid; k < n_pre; k += kTileThreads) {
+            int32_t item = out[k];
             if (item < -1) {  // deferred: global entry index, entry record
                 uint32_t ord = (uint32_t)(-2 - item);
                 const bool slow = ord >= kSlowBase;
@@ -1108,8 +1157,8 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
             uint64_t w0 = W.slow[ei].scan_from;
             uint64_t end = doc_end;
             for (;;) {
-                const uint64_t g_lo = w0 - kBack;
-                const uint64_t g_hi = g_lo + kRegion < doc_end ? g_lo + kRegion : doc_end;
+                const uint64_t g_lo = w0 - kSBack;
+                const uint64_t g_hi = g_lo + kSRegion < doc_end ? g_lo + kSRegion : doc_end;
                 const int n = (int)(g_hi - g_lo);
                 const bool hard = g_hi == doc_end;
                 const int eval_hi = hard ? n : n - kEvalSlack;
@@ -1123,7 +1172,7 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
                 int found = n;
                 for (int j = 0; j < kPer; j++) {
                     int q = c0 + j;
-                    if (q < kBack || q >= eval_hi) continue;
+                    if (q < kSBack || q >= eval_hi) continue;
                     uint32_t w = R.a[q];
                     if (!(w & I_RUNE) || (w & I_SPBODY)) continue;
                     // a pre-token this long holds no digit, so no digit-run offset is needed
