@@ -43,7 +43,7 @@ struct l3_ctx {
     HostTables H;
     Tables T{};
     DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes;
-    DevBuf w_stream, w_items, w_extra, w_base, w_doc0, w_docitem, w_slow, w_miss, w_missres, w_pool, w_scratch, w_status;
+    DevBuf w_stream, w_items, w_extra, w_base, w_pre, w_flag, w_doc0, w_docitem, w_slow, w_miss, w_missres, w_pool, w_scratch, w_status;
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
     uint64_t slow_cap = 0, miss_shard_cap = 0, pool_cap = 0, scratch_cap = 0;
     Status* h_status = nullptr;          // pinned
@@ -109,7 +109,9 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     HIPCHK(c, c->w_stream.ensure(n_tiles * kTileCap * sizeof(int32_t)));
     HIPCHK(c, c->w_items.ensure(n_tiles * 4));
     HIPCHK(c, c->w_extra.ensure(n_tiles * 4));
-    HIPCHK(c, c->w_base.ensure((n_tiles + 1) * 8));
+    HIPCHK(c, c->w_base.ensure((n_tiles / 1024 + 2) * 8));
+    HIPCHK(c, c->w_pre.ensure(n_tiles * 8));
+    HIPCHK(c, c->w_flag.ensure(n_tiles * 4));
     HIPCHK(c, c->w_doc0.ensure((n_tiles + 1) * 4));
     HIPCHK(c, c->w_docitem.ensure((n_docs + 1) * 4));
     HIPCHK(c, c->w_status.ensure(sizeof(Status)));
@@ -128,6 +130,8 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     W.tile_items = c->w_items.as<uint32_t>();
     W.tile_extra = c->w_extra.as<uint32_t>();
     W.tile_base = c->w_base.as<uint64_t>();
+    W.tile_pre = c->w_pre.as<uint64_t>();
+    W.tile_flag = c->w_flag.as<uint32_t>();
     W.tile_doc0 = c->w_doc0.as<uint32_t>();
     W.doc_item = c->w_docitem.as<uint32_t>();
     W.slow = c->w_slow.as<SlowEntry>();
@@ -266,7 +270,7 @@ void l3_destroy(l3_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
                       &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_stream, &c->w_items, &c->w_miss, &c->w_missres,
-                      &c->w_extra, &c->w_base, &c->w_doc0, &c->w_docitem, &c->w_slow, &c->w_pool, &c->w_scratch,
+                      &c->w_extra, &c->w_base, &c->w_pre, &c->w_flag, &c->w_doc0, &c->w_docitem, &c->w_slow, &c->w_pool, &c->w_scratch,
                       &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
                       &c->s_total};
     for (DevBuf* b : bufs) b->release();

@@ -24,23 +24,39 @@ L3_HD uint32_t pair_pick(uint64_t key, const PairBucket& u, const PairBucket& v)
 L3_HD uint32_t pair_prio(const Tables& t, uint32_t a, uint32_t b) {
     const uint64_t key = pair_key(a, b);
     uint32_t b1, b2;
-    pair_hash2(key, t.pair_log2, &b1, &b2);
+    pair_hash2(a, b, t.pair_log2, &b1, &b2);
+#if defined(L3_EXP_NOPROBE)
+    return kNoPrio;
+#elif defined(L3_EXP_ONEBUCKET)
+    const PairBucket u = t.pair_buckets[b1];
+    return pair_pick(key, u, u);
+#else
     const PairBucket u = t.pair_buckets[b1];
     const PairBucket v = t.pair_buckets[b2];
     return pair_pick(key, u, v);
+#endif
 }
 // two independent probes: four loads in flight together
 L3_HD void pair_prio2(const Tables& t, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t* r0, uint32_t* r1) {
     const uint64_t k0 = pair_key(a0, b0), k1 = pair_key(a1, b1);
     uint32_t p0, q0, p1, q1;
-    pair_hash2(k0, t.pair_log2, &p0, &q0);
-    pair_hash2(k1, t.pair_log2, &p1, &q1);
+    pair_hash2(a0, b0, t.pair_log2, &p0, &q0);
+    pair_hash2(a1, b1, t.pair_log2, &p1, &q1);
+#if defined(L3_EXP_NOPROBE)
+    *r0 = kNoPrio; *r1 = kNoPrio;
+#elif defined(L3_EXP_ONEBUCKET)
+    const PairBucket u0 = t.pair_buckets[p0];
+    const PairBucket u1 = t.pair_buckets[p1];
+    *r0 = pair_pick(k0, u0, u0);
+    *r1 = pair_pick(k1, u1, u1);
+#else
     const PairBucket u0 = t.pair_buckets[p0];
     const PairBucket v0 = t.pair_buckets[q0];
     const PairBucket u1 = t.pair_buckets[p1];
     const PairBucket v1 = t.pair_buckets[q1];
     *r0 = pair_pick(k0, u0, v0);
     *r1 = pair_pick(k1, u1, v1);
+#endif
 }
 
 // Whole-string probe for a string of <= 12 bytes given as three zero-padded words: four independent slot loads.

@@ -36,9 +36,23 @@ L3_HD uint32_t prio_merged_id(uint32_t prio) { return prio >> 7; }
 constexpr uint64_t kPairEmpty = ~0ull;
 struct alignas(16) PairBucket { uint64_t s[2]; };
 L3_HD uint64_t pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << 17) | (uint64_t)b; }
-L3_HD void pair_hash2(uint64_t key, uint32_t log2_buckets, uint32_t* b1, uint32_t* b2) {
-    *b1 = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2_buckets));
-    *b2 = (uint32_t)(((key ^ (key >> 15)) * 0xD6E8FEB86659FD93ull) >> (64 - log2_buckets));
+// low 32 bits of the product of the low 24 bits of a and b: one full-rate v_mul_u32_u24 on the GPU (a 32 x 32
+// multiply costs four of them)
+L3_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu));
+#endif
+}
+// two bucket indices of the pair (idA, idB), ids < 2^17.  Six ALU operations each.
+L3_HD void pair_hash2(uint32_t a, uint32_t b, uint32_t log2_buckets, uint32_t* b1, uint32_t* b2) {
+    uint32_t x = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu);
+    uint32_t y = mul24(a, 0xC2B2AFu) + mul24(b, 0x27D4EBu) + 0x165667B1u;
+    x ^= x >> 11;
+    y ^= y >> 13;
+    *b1 = mul24(x, 0xD6E8FFu) >> (32 - log2_buckets);
+    *b2 = mul24(y, 0x7FEB35u) >> (32 - log2_buckets);
 }
 
 // ---- vocabulary table: raw token bytes -> id, two-choice (cuckoo) hashing, 32-byte buckets of two slots --

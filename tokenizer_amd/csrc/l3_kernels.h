@@ -64,18 +64,23 @@ struct Status {
     uint32_t miss_count[64];
 };
 constexpr int kMissShards = 64;
-// a short deferred pre-token (input of merge_kernel); its result is miss_res[i] = pool offset << 8 | tokens
-struct MissIn {
-    uint64_t start;   // global byte offset
+// a short deferred pre-token (input of merge_kernel).  Its result is one word of miss_res: bits 0..7 = n tokens;
+// n <= 3: the tokens themselves in bits 8.., 17 bits each; n > 3: bits 8.. = offset of the tokens in the pool
+struct alignas(16) MissIn {
     uint32_t tile;    // owning tile
     uint32_t len;     // bytes (<= kLaneMax), valid UTF-8
+    uint64_t start;   // global byte offset
+    uint32_t w[4];    // its first 16 bytes as little-endian words (bytes past len: unspecified)
 };
+constexpr uint32_t kMissInline = 3;   // results of up to this many tokens live in the miss_res word itself
 
 struct Workspace {
     int32_t* stream;        // [n_tiles * kTileCap] per-tile token stream incl. slow placeholders
     uint32_t* tile_items;   // [n_tiles] items in the tile's stream
     uint32_t* tile_extra;   // [n_tiles] sum of (tokens - 1) over the tile's deferred pre-tokens (atomic adds)
     uint64_t* tile_base;    // [ceil(n_tiles / 1024)] exclusive scan of the token totals of blocks of 1024 tiles
+    uint64_t* tile_pre;     // [n_tiles] tokens of the tiles of the same block that precede the tile
+    uint32_t* tile_flag;    // [n_tiles] 1 = the fast emit kernel left the tile to the generic one
     uint32_t* tile_doc0;    // [n_tiles + 1] first document whose start is >= the tile start
     uint32_t* doc_item;     // [n_docs + 1] stream index (inside its tile) of the document's first item
     SlowEntry* slow;        // [slow_cap]

@@ -828,6 +828,13 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                         mi.start = g_lo + (uint64_t)s;
                         mi.tile = (uint32_t)tile;
                         mi.len = (uint32_t)(e - s);
+                        {   // the first 16 bytes ride along (LDS image, unaligned start), so the merge kernel reads no text
+                            const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
+                            const uint32_t sh = (uint32_t)(s & 3) * 8u;
+                            const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3], x4 = wp[4];
+                            mi.w[0] = __funnelshift_r(x0, x1, sh); mi.w[1] = __funnelshift_r(x1, x2, sh);
+                            mi.w[2] = __funnelshift_r(x2, x3, sh); mi.w[3] = __funnelshift_r(x3, x4, sh);
+                        }
                         W.miss_in[ei] = mi;
                     }
                 }
@@ -866,6 +873,13 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                         mi.start = g_lo + (uint64_t)s;
                         mi.tile = (uint32_t)tile;
                         mi.len = (uint32_t)(e - s);
+                        {   // the first 16 bytes ride along (LDS image, unaligned start), so the merge kernel reads no text
+                            const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
+                            const uint32_t sh = (uint32_t)(s & 3) * 8u;
+                            const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3], x4 = wp[4];
+                            mi.w[0] = __funnelshift_r(x0, x1, sh); mi.w[1] = __funnelshift_r(x1, x2, sh);
+                            mi.w[2] = __funnelshift_r(x2, x3, sh); mi.w[3] = __funnelshift_r(x3, x4, sh);
+                        }
                         W.miss_in[ei] = mi;
                     }
                 }
@@ -894,23 +908,96 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
 }
 
 // ---- the merge kernel: short deferred pre-tokens, one lane each -------------------------------------------
-// Every lane runs the greedy merge loop (bpe.go:36-71) of one pre-token of <= kLaneMax bytes on its own span
-// of a shared LDS symbol array (spans laid out by a prefix sum of the lengths), so all 64 lanes of a wave
-// keep independent probe chains in flight.
+// Every lane runs the greedy merge loop (bpe.go:36-71) of one pre-token in its own slot of an LDS arena, so all 64
+// lanes of a wave keep independent probe chains in flight.  A slot holds S elements of two words:
+//   sy = token id | next live element << 17 | previous live element << 24     (a linked list, 127 = none)
+//   pq = prio24 of the pair (element, next live element) << 7 | element index  (0xFFFFFFFF = no such rule)
+// so the smallest pq of a slot IS the next merge of the reference order: smallest rank, leftmost among equals
+// (bpe.go:126, priority_queue.go:20-25).  Slots are S + 1 words apart: all lanes touch element p of their slot
+// in the same instruction, and an odd stride puts them on different LDS banks.
+// Pre-tokens of up to 16 bytes (their bytes arrive inside the MissIn record) use 16-element slots, all 256 lanes
+// at once; longer ones (<= kLaneMax = 64 bytes, bytes read from the text) follow in groups of 64 lanes with
+// 64-element slots of the same arena.
 #ifndef L3_MERGE_THREADS
 #define L3_MERGE_THREADS 256
-#define L3_MERGE_SYMS 4096
 #endif
 constexpr int kMergeThreads = L3_MERGE_THREADS;
-constexpr int kMergeSyms = L3_MERGE_SYMS;
 constexpr int kMergeWaves = kMergeThreads / 64;
+constexpr int kMergeArena = kMergeThreads * 17;   // words per array; also holds 64 slots of 65
+constexpr uint32_t kNone = 127;
+static_assert(kMergeArena >= 64 * 65 || kMergeThreads < 256, "arena must hold one group of long slots");
+
+template <int S>
+__device__ __forceinline__ void lane_merge(const Tables& T, uint32_t* sy, uint32_t* pq) {
+    for (;;) {
+        uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int p = 0; p < S; p++) best = min(best, pq[p]);
+        if (best == 0xFFFFFFFFu) return;
+        const uint32_t bp = best & 127u, m = best >> 14;        // prio24 >> 7 = merged id
+        const uint32_t wb = sy[bp];
+        const uint32_t q = (wb >> 17) & 127u, l = (wb >> 24) & 127u;
+        const uint32_t r = (sy[q] >> 17) & 127u;
+        sy[bp] = m | (r << 17) | (l << 24);
+        pq[q] = 0xFFFFFFFFu;
+        uint32_t idr = 0, idl = 0;
+        if (r != kNone) { const uint32_t wr = sy[r]; idr = wr & 0x1FFFFu; sy[r] = (wr & 0x00FFFFFFu) | (bp << 24); }
+        if (l != kNone) idl = sy[l] & 0x1FFFFu;
+        uint32_t pa = kNoPrio, pb = kNoPrio;
+        if (r != kNone && l != kNone) pair_prio2(T, m, idr, idl, m, &pa, &pb);
+        else if (r != kNone) pa = pair_prio(T, m, idr);
+        else if (l != kNone) pb = pair_prio(T, idl, m);
+        pq[bp] = pa == kNoPrio ? 0xFFFFFFFFu : (pa << 7) | bp;
+        if (l != kNone) pq[l] = pb == kNoPrio ? 0xFFFFFFFFu : (pb << 7) | l;
+    }
+}
+
+// Stores the result of a finished slot: miss_res word (tokens inline or in the pool), tile_extra.  All lanes of
+// the wave call it together (`act`: this lane has a result); pool space is one atomic per wave.
+__device__ __forceinline__ void lane_finish(const Workspace& W, const uint32_t* sy, bool act, uint64_t ei, uint32_t tile) {
+    uint32_t n_out = 0;
+    uint64_t inl = 0;
+    if (act) {
+        uint32_t p = 0;
+        while (p != kNone) {
+            const uint32_t w = sy[p];
+            if (n_out < kMissInline) inl |= (uint64_t)(w & 0x1FFFFu) << (17u * n_out);
+            n_out++;
+            p = (w >> 17) & 127u;
+        }
+    }
+    const uint32_t need = (act && n_out > kMissInline) ? n_out : 0u;
+    const uint32_t inc = wave_iscan(need);
+    const uint32_t wtot = __shfl(inc, 63, 64);
+    unsigned long long wbase = 0;
+    if (wtot) {   // uniform over the wave
+        if (lane_id() == 63) wbase = atomicAdd(&W.status->pool_used, (unsigned long long)wtot);
+        wbase = __shfl(wbase, 63, 64);
+    }
+    if (!act) return;
+    if (need) {
+        const unsigned long long dst = wbase + inc - need;
+        if (dst + n_out <= W.pool_cap) {
+            uint32_t p = 0, k = 0;
+            while (p != kNone) {
+                const uint32_t w = sy[p];
+                W.pool[dst + k++] = (int32_t)(w & 0x1FFFFu);
+                p = (w >> 17) & 127u;
+            }
+        } else {
+            atomicOr(&W.status->flags, kOvfPool);
+        }
+        inl = dst;
+    }
+    W.miss_res[ei] = (inl << 8) | n_out;
+    if (n_out > 1) atomicAdd(&W.tile_extra[tile], n_out - 1);
+}
+
 __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspace W, EncodeArgs A) {
-    __shared__ int32_t sym[kMergeSyms];
-    __shared__ uint32_t pr[kMergeSyms];
+    __shared__ uint32_t sy_a[kMergeArena];
+    __shared__ uint32_t pq_a[kMergeArena];
     __shared__ uint8_t byte_tok[256];
     __shared__ uint32_t tmp[16];
-    __shared__ unsigned long long tmp64[8];
-    __shared__ unsigned long long pool_base;
     if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x;
     for (int i = tid; i < 256; i += kMergeThreads) byte_tok[i] = T.byte_tok[i];
@@ -923,59 +1010,63 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
     for (uint64_t chunk = (uint64_t)(blockIdx.x / kMissShards) * kMergeThreads; chunk < n_ent; chunk += stride) {
         const bool have = chunk + tid < n_ent;
         const uint64_t ei = shard * W.miss_shard_cap + chunk + tid;
-        uint64_t start = 0;
-        uint32_t len = 0, tile = 0;
-        if (have) { const MissIn mi = W.miss_in[ei]; start = mi.start; len = mi.len; tile = mi.tile; }
-        uint32_t total;
-        const uint32_t off = block_escan<kMergeWaves>(len, tmp, &total);
-        bool done = !have || len == 0;
-        uint32_t base = 0, n_out = 0;
-        int32_t toks[4];  // first tokens kept in registers until the pool slot is known; the rest re-read from LDS
-#pragma unroll 1
-        for (;;) {
-            const bool act = !done && off >= base && off + len <= base + (uint32_t)kMergeSyms;
-            int s = 0, e = 0;
+        MissIn mi;
+        mi.len = 0; mi.tile = 0; mi.start = 0; mi.w[0] = mi.w[1] = mi.w[2] = mi.w[3] = 0;
+        if (have) mi = W.miss_in[ei];
+        const uint32_t len = mi.len;
+        // ---- up to 16 bytes: every lane in its own 16-element slot
+        {
+            const bool act = have && len >= 1 && len <= 16;
+            uint32_t* sy = sy_a + tid * 17;
+            uint32_t* pq = pq_a + tid * 17;
             if (act) {
-                s = (int)(off - base); e = s + (int)len;
-                const uint8_t* src = A.text + start;
-                for (int i = 0; i < (int)len; i += 8) {
-                    uint32_t bb[9];
+                uint32_t bb[16], pp[15];
 #pragma unroll
-                    for (int j = 0; j < 9; j++) bb[j] = (i + j < (int)len) ? (uint32_t)src[i + j] : 0x100u;
-                    uint32_t pp[8];
+                for (int j = 0; j < 16; j++) bb[j] = (mi.w[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) pp[j] = (bb[j + 1] < 0x100u && bb[j] < 0x100u) ? T.bytepair[(bb[j] << 8) | bb[j + 1]] : kNoPrio;
+                for (int j = 0; j < 15; j++) pp[j] = (uint32_t)(j + 1) < len ? T.bytepair[(bb[j] << 8) | bb[j + 1]] : kNoPrio;
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (i + j < (int)len) { sym[s + i + j] = byte_tok[bb[j]]; pr[s + i + j] = pp[j]; }
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t nxt = (uint32_t)(j + 1) < len ? (uint32_t)(j + 1) : kNone, prv = j ? (uint32_t)(j - 1) : kNone;
+                    sy[j] = (uint32_t)byte_tok[bb[j]] | (nxt << 17) | (prv << 24);
+                    pq[j] = (j < 15 && pp[j < 15 ? j : 0] != kNoPrio && (uint32_t)j < len) ? (pp[j < 15 ? j : 0] << 7) | (uint32_t)j : 0xFFFFFFFFu;
                 }
-                if (!L3_DBG(A.flags, 0x100u)) merge_span(T, sym, pr, s, e);
-                n_out = 0;
-                for (int i = s; i < e; i++) n_out += sym[i] >= 0 ? 1u : 0u;
+                lane_merge<16>(T, sy, pq);
             }
-            // pool space for this window's tokens: one atomic per workgroup
-            uint32_t wtot;
-            const uint32_t po = block_escan<kMergeWaves>(act ? n_out : 0u, tmp, &wtot);
-            if (tid == 0) pool_base = wtot ? atomicAdd(&W.status->pool_used, (unsigned long long)wtot) : 0ull;
-            __syncthreads();
-            if (act) {
-                const unsigned long long dst = pool_base + po;
-                if (dst + n_out <= W.pool_cap) {
-                    uint32_t k = 0;
-                    for (int i = s; i < e; i++)
-                        if (sym[i] >= 0) W.pool[dst + k++] = sym[i];
-                } else {
-                    atomicOr(&W.status->flags, kOvfPool);
-                }
-                W.miss_res[ei] = ((uint64_t)dst << 8) | n_out;
-                if (n_out > 1) atomicAdd(&W.tile_extra[tile], n_out - 1);
-                done = true;
-            }
-            const unsigned long long nxt = block_min64<kMergeWaves>(done ? ~0ull : (unsigned long long)off, tmp64);
-            if (nxt == ~0ull) break;
-            base = (uint32_t)nxt;
+            lane_finish(W, sy, act, ei, mi.tile);
         }
-        (void)toks;
+        // ---- 17..64 bytes: groups of 64 lanes, 64-element slots of the same arena
+        const bool is_long = have && len > 16;
+        const int n_long = __syncthreads_count(is_long);   // also: everyone is done with the short slots
+        if (n_long) {
+            uint32_t tot;
+            const uint32_t ord = block_escan<kMergeWaves>(is_long ? 1u : 0u, tmp, &tot);
+#pragma unroll 1
+            for (uint32_t g = 0; g * 64u < (uint32_t)n_long; g++) {
+                const bool act = is_long && ord / 64u == g;
+                uint32_t* sy = sy_a + (ord % 64u) * 65u;
+                uint32_t* pq = pq_a + (ord % 64u) * 65u;
+                if (act) {
+                    const uint8_t* src = A.text + mi.start;
+                    uint32_t prev = src[0];
+                    for (uint32_t j = 0; j < 64; j++) {
+                        if (j < len) {
+                            const uint32_t cur = j + 1 < len ? (uint32_t)src[j + 1] : 0u;
+                            const uint32_t pr = j + 1 < len ? T.bytepair[(prev << 8) | cur] : kNoPrio;
+                            sy[j] = (uint32_t)byte_tok[prev] | ((j + 1 < len ? j + 1 : kNone) << 17) | ((j ? j - 1 : kNone) << 24);
+                            pq[j] = pr != kNoPrio ? (pr << 7) | j : 0xFFFFFFFFu;
+                            prev = cur;
+                        } else {
+                            pq[j] = 0xFFFFFFFFu;
+                        }
+                    }
+                    lane_merge<64>(T, sy, pq);
+                }
+                // all four waves take part (lanes of a group are spread over them)
+                lane_finish(W, sy, act, ei, mi.tile);
+                __syncthreads();
+            }
+        }
         __syncthreads();
     }
 }
@@ -1277,20 +1368,28 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
 // ---- per-tile output bases: block totals, scan of the block totals -----------------------------------------
 constexpr int kScanThreads = 1024;
 constexpr int kScanBlock = 1024;  // tiles per block total
-__global__ __launch_bounds__(256) void block_totals_kernel(Workspace W, uint64_t n_tiles) {
-    __shared__ unsigned long long red[4];
+__global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, uint64_t n_tiles) {
+    __shared__ unsigned long long wsum[kScanBlock / 64];
     if (W.status->flags & kBadOffsets) return;
-    const uint64_t t0 = (uint64_t)blockIdx.x * kScanBlock;
-    unsigned long long v = 0;
-    for (int j = 0; j < kScanBlock / 256; j++) {
-        uint64_t t = t0 + (uint64_t)j * 256 + threadIdx.x;
-        if (t < n_tiles) v += (unsigned long long)W.tile_items[t] + W.tile_extra[t];
-    }
+    const uint64_t t = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;   // one tile per thread
+    const unsigned long long v = t < n_tiles ? (unsigned long long)W.tile_items[t] + W.tile_extra[t] : 0ull;
+    unsigned long long inc = v;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    if (lane_id() == 0) red[wave_id()] = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane_id() >= d) inc += o;
+    }
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) W.tile_base[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    unsigned long long pre = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kScanBlock / 64; i++) {
+        const unsigned long long x = wsum[i];
+        if (i < (int)(threadIdx.x >> 6)) pre += x;
+        tot += x;
+    }
+    if (t < n_tiles) W.tile_pre[t] = pre + inc - v;
+    if (threadIdx.x == 0) W.tile_base[blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeArgs A, uint64_t n_blocks) {
     __shared__ unsigned long long wsum[kScanThreads / 64];
@@ -1331,17 +1430,23 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeA
 
 // ---- final scatter -------------------------------------------------------------------------------------
 constexpr int kEmitQueue = 128;
-// (pool offset, token count) of a deferred pre-token
-__device__ __forceinline__ void deferred_result(const Workspace& W, int32_t item, uint64_t* pool_off, uint32_t* count) {
+// Token count of a deferred pre-token and where its tokens are: *inl = they are the 17-bit fields of *loc
+// (merge_kernel results of up to kMissInline tokens), else *loc = their offset in the pool
+__device__ __forceinline__ void deferred_result(const Workspace& W, int32_t item, uint64_t* loc, uint32_t* count, bool* inl) {
     const uint32_t e = (uint32_t)(-2 - item);
     if (e >= kSlowBase) {
-        *pool_off = W.slow[e - kSlowBase].pool_off;
+        *loc = W.slow[e - kSlowBase].pool_off;
         *count = W.slow[e - kSlowBase].count;
+        *inl = false;
     } else {
         const uint64_t r = W.miss_res[e];
-        *pool_off = r >> 8;
+        *loc = r >> 8;
         *count = (uint32_t)(r & 0xFFu);
+        *inl = *count <= kMissInline;
     }
+}
+__device__ __forceinline__ int32_t deferred_token(const Workspace& W, uint64_t loc, bool inl, uint32_t k) {
+    return inl ? (int32_t)((loc >> (17u * k)) & 0x1FFFFu) : W.pool[loc + k];
 }
 // exclusive scan of two 32-bit counters packed in one 64-bit word; tmp: >= 4 words.  Two barriers.
 __device__ __forceinline__ unsigned long long block_escan64(unsigned long long v, unsigned long long* tmp, unsigned long long* total) {
@@ -1364,13 +1469,24 @@ __device__ __forceinline__ unsigned long long block_escan64(unsigned long long v
     *total = tot;
     return base + inc - v;
 }
+// ---- final scatter, fast path ---------------------------------------------------------------------------
+// One workgroup per tile, four consecutive items per thread.  The tile's tokens, BOS and EOS are assembled in an
+// LDS staging buffer at their position relative to the tile's first output slot and leave as one contiguous,
+// coalesced run.  Document starts are a bit per item (tiles with several documents on one item go to the
+// generic kernel, as do tiles with more tokens than the staging buffer holds).
+constexpr int kStage = 3072;
+constexpr int kEmitItemsPer = 4;
+constexpr int kEmitRound = kTileThreads * kEmitItemsPer;
+constexpr int kDmaskWords = (kTileCap + 64) / 64 + 1;
+static_assert(kDmaskWords <= 64, "one wave scans the document-start words");
 __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeArgs A) {
-    __shared__ uint32_t docinc[kTileCap + 1];
-    __shared__ uint32_t tokpre[kTileCap + 1];
+    __shared__ int32_t stg[kStage];
+    __shared__ unsigned long long dmask[kDmaskWords];
+    __shared__ uint32_t wordpre[kDmaskWords];
     __shared__ unsigned long long tmp64[8];
-    __shared__ unsigned long long q_out[kEmitQueue];
+    __shared__ unsigned long long q_rel[kEmitQueue];
     __shared__ int32_t q_item[kEmitQueue];
-    __shared__ uint32_t q_n;
+    __shared__ uint32_t q_n, s_generic;
 
     const uint32_t fl = W.status->flags;
     if (fl & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) return;
@@ -1378,6 +1494,129 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
     const int tid = threadIdx.x;
     const uint64_t tile = blockIdx.x;
     const bool last_tile = tile + 1 == gridDim.x;
+    const uint32_t n_items = W.tile_items[tile];
+    const uint64_t n_tok = (uint64_t)n_items + W.tile_extra[tile];
+    const uint64_t d_lo = W.tile_doc0[tile];
+    const uint64_t d_hi = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
+    const uint32_t bos = A.flags & 1u, eos = (A.flags >> 1) & 1u, be = bos + eos;
+    const unsigned long long base = W.tile_base[tile / kScanBlock] + W.tile_pre[tile];
+    const int32_t* in = W.stream + tile * (uint64_t)kTileCap;
+    const uint64_t n_tdocs = d_hi - d_lo;
+    if (n_tok + (n_tdocs + 1) * be > (uint64_t)kStage || n_tdocs > (uint64_t)n_items + 1) {
+        if (tid == 0) W.tile_flag[tile] = 1;
+        return;
+    }
+    if (tid < kDmaskWords) dmask[tid] = 0;
+    if (tid == 0) { q_n = 0; s_generic = 0; }
+    __syncthreads();
+    for (uint64_t d = d_lo + tid; d < d_hi; d += kTileThreads) {
+        const uint32_t it = W.doc_item[d];
+        atomicOr(&dmask[it >> 6], 1ull << (it & 63));
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint32_t c = tid < kDmaskWords ? (uint32_t)__popcll(dmask[tid]) : 0u;
+        const uint32_t inc = wave_iscan(c);
+        if (tid < kDmaskWords) wordpre[tid] = inc - c;
+        if (tid == 63 && inc != (uint32_t)n_tdocs) s_generic = 1;   // two documents start at one item
+    }
+    __syncthreads();
+    if (s_generic) {
+        if (tid == 0) W.tile_flag[tile] = 1;
+        return;
+    }
+    if (tid == 0) W.tile_flag[tile] = 0;
+    // output slot of staging index 0 (may be -1 for the first tile; nothing is staged below rel_lo then)
+    const long long o_base = (long long)base + (long long)d_lo * be - be + bos;
+
+    unsigned long long carry = 0;  // low 32: tokens, high 32: documents started
+    const uint32_t rounds = (n_items + 1 + kEmitRound - 1) / kEmitRound;
+#pragma unroll 1
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i0 = r * kEmitRound + (uint32_t)tid * kEmitItemsPer;
+        int32_t item[kEmitItemsPer];
+        if (i0 + kEmitItemsPer <= n_items) {
+            const int4 v = *reinterpret_cast<const int4*>(in + i0);
+            item[0] = v.x; item[1] = v.y; item[2] = v.z; item[3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kEmitItemsPer; j++) item[j] = i0 + j < n_items ? in[i0 + j] : kDead;
+        }
+        uint32_t cnt[kEmitItemsPer];
+        uint64_t poff[kEmitItemsPer];
+        bool inl[kEmitItemsPer];
+#pragma unroll
+        for (int j = 0; j < kEmitItemsPer; j++) {
+            cnt[j] = item[j] >= 0 ? 1u : 0u;
+            poff[j] = 0;
+            inl[j] = false;
+            if (item[j] < kDead) deferred_result(W, item[j], &poff[j], &cnt[j], &inl[j]);
+        }
+        const uint32_t dbits = i0 <= n_items ? (uint32_t)(dmask[i0 >> 6] >> (i0 & 63)) & 0xFu : 0u;  // i0 % 4 == 0: one word
+        const uint32_t dprev = i0 <= n_items ? wordpre[i0 >> 6] + (uint32_t)__popcll(dmask[i0 >> 6] & ((1ull << (i0 & 63)) - 1ull)) : 0u;
+        const uint32_t csum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        unsigned long long tot;
+        const unsigned long long ex = carry + block_escan64((unsigned long long)csum, tmp64, &tot);
+        carry += tot;
+        uint32_t tp = (uint32_t)ex;
+#pragma unroll
+        for (int j = 0; j < kEmitItemsPer; j++) {
+            const uint32_t i = i0 + j;
+            const uint32_t dp = dprev + (uint32_t)__popc(dbits & ((2u << j) - 1u));  // documents that start at or before item i
+            const uint32_t rel = tp + dp * be;
+            if (i <= n_items && ((dbits >> j) & 1u)) {   // a document starts here (tokenizer.go:225-229,258-262)
+                const uint64_t d = d_lo + dp - 1;
+                A.out_off[d] = base + tp + d * be;
+                if (bos && d < A.n_docs) stg[rel - bos] = kBosId;
+                if (eos && d > 0) stg[rel - bos - 1] = kEosId;
+            }
+            if (i < n_items) {
+                if (item[j] >= 0) {
+                    stg[rel] = item[j];
+                } else if (cnt[j] <= 64) {
+                    for (uint32_t k = 0; k < cnt[j]; k++) stg[rel + k] = deferred_token(W, poff[j], inl[j], k);
+                } else {
+                    const uint32_t qi = atomicAdd(&q_n, 1u);
+                    if (qi < kEmitQueue) { q_rel[qi] = rel; q_item[qi] = item[j]; }
+                }
+            }
+            tp += cnt[j];
+        }
+    }
+    __syncthreads();
+    // long runs of tokens from the pool: copied by the whole workgroup (more than 64 tokens = more than 64 bytes,
+    // so one tile holds fewer than kEmitQueue of them)
+    const uint32_t qn = q_n < kEmitQueue ? q_n : kEmitQueue;
+    for (uint32_t qi = 0; qi < qn; qi++) {
+        uint64_t po; uint32_t cn; bool il;
+        deferred_result(W, q_item[qi], &po, &cn, &il);
+        const uint32_t rel = (uint32_t)q_rel[qi];
+        for (uint32_t k = tid; k < cn; k += kTileThreads) stg[rel + k] = W.pool[po + k];
+    }
+    if (qn) __syncthreads();
+    // what this tile staged: [rel_lo, rel_hi)
+    const bool starts0 = (dmask[0] & 1ull) != 0;
+    const uint32_t rel_lo = (starts0 && eos && d_lo == 0) ? 1u : 0u;
+    const bool slot_doc = (dmask[n_items >> 6] >> (n_items & 63)) & 1ull;   // a document starts after the last item
+    const uint32_t d_in = (uint32_t)n_tdocs - (slot_doc ? 1u : 0u);
+    uint32_t rel_hi = (uint32_t)n_tok + d_in * be;
+    if (slot_doc) {
+        const uint64_t d = d_hi - 1;
+        if (bos && d < A.n_docs) rel_hi = (uint32_t)n_tok + d_in * be + eos + 1u;
+        else if (eos && d > 0) rel_hi += 1u;
+    }
+    for (uint32_t r = rel_lo + (uint32_t)tid; r < rel_hi; r += kTileThreads) A.out_tok[o_base + (long long)r] = stg[r];
+}
+
+// Tiles the fast kernel leaves (W.tile_flag): several documents starting at one item (empty documents), or more tokens
+// than its staging buffer holds.  One workgroup looks after kGenericPer consecutive tiles.
+constexpr int kGenericPer = 16;
+__device__ void emit_tile_generic(const Workspace& W, const EncodeArgs& A, uint64_t tile, uint64_t n_tiles, uint32_t* docinc,
+                                  uint32_t* tokpre, unsigned long long* tmp64, unsigned long long* q_out, int32_t* q_item,
+                                  uint32_t* q_n_p) {
+    uint32_t& q_n = *q_n_p;
+    const int tid = threadIdx.x;
+    const bool last_tile = tile + 1 == n_tiles;
     const uint32_t n_items = W.tile_items[tile];
     const uint64_t d_lo = W.tile_doc0[tile];
     const uint64_t d_hi = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
@@ -1387,17 +1626,7 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
     for (int i = tid; i <= (int)n_items; i += kTileThreads) docinc[i] = 0;
     if (tid == 0) q_n = 0;
     // tokens before this tile: scanned block base + the tiles of the block that precede it
-    unsigned long long base;
-    {
-        const uint64_t blk = tile / kScanBlock, t0 = blk * kScanBlock;
-        unsigned long long v = 0;
-        for (uint64_t t = t0 + tid; t < tile; t += kTileThreads) v += (unsigned long long)W.tile_items[t] + W.tile_extra[t];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        if (lane_id() == 0) tmp64[4 + wave_id()] = v;
-        __syncthreads();
-        base = W.tile_base[blk] + tmp64[4] + tmp64[5] + tmp64[6] + tmp64[7];
-    }
+    const unsigned long long base = W.tile_base[tile / kScanBlock] + W.tile_pre[tile];
     for (uint64_t d = d_lo + tid; d < d_hi; d += kTileThreads) atomicAdd(&docinc[W.doc_item[d]], 1u);
     __syncthreads();
 
@@ -1410,7 +1639,8 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
         const int32_t item = i < n_items ? in[i] : kDead;
         uint32_t cnt = item >= 0 ? 1u : 0u;
         uint64_t poff = 0;
-        if (item < kDead) deferred_result(W, item, &poff, &cnt);
+        bool inl = false;
+        if (item < kDead) deferred_result(W, item, &poff, &cnt, &inl);
         const uint32_t dinc = i <= n_items ? docinc[i] : 0u;
         unsigned long long tot;
         const unsigned long long ex = carry + block_escan64(((unsigned long long)dinc << 32) | cnt, tmp64, &tot);
@@ -1424,7 +1654,7 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
             if (item >= 0) {
                 A.out_tok[o] = item;
             } else if (cnt <= 64) {
-                for (uint32_t k = 0; k < cnt; k++) A.out_tok[o + k] = W.pool[poff + k];
+                for (uint32_t k = 0; k < cnt; k++) A.out_tok[o + k] = deferred_token(W, poff, inl, k);
             } else {
                 uint32_t qi = atomicAdd(&q_n, 1u);
                 if (qi < kEmitQueue) { q_out[qi] = o; q_item[qi] = item; }
@@ -1443,12 +1673,30 @@ __global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeA
     // tokens has more than 21 bytes, so one tile holds fewer than kEmitQueue of them)
     const uint32_t qn = q_n < kEmitQueue ? q_n : kEmitQueue;
     for (uint32_t qi = 0; qi < qn; qi++) {
-        uint64_t po; uint32_t cn;
-        deferred_result(W, q_item[qi], &po, &cn);
+        uint64_t po; uint32_t cn; bool il;
+        deferred_result(W, q_item[qi], &po, &cn, &il);
         const uint64_t o = q_out[qi];
         for (uint32_t k = tid; k < cn; k += kTileThreads) A.out_tok[o + k] = W.pool[po + k];
     }
 }
+__global__ __launch_bounds__(kTileThreads) void emit_generic_kernel(Workspace W, EncodeArgs A, uint64_t n_tiles) {
+    __shared__ uint32_t docinc[kTileCap + 1];
+    __shared__ uint32_t tokpre[kTileCap + 1];
+    __shared__ unsigned long long tmp64[8];
+    __shared__ unsigned long long q_out[kEmitQueue];
+    __shared__ int32_t q_item[kEmitQueue];
+    __shared__ uint32_t q_n;
+    const uint32_t fl = W.status->flags;
+    if (fl & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) return;
+    if (W.status->total_tokens > A.out_cap) return;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kGenericPer;
+    for (uint64_t t = t0; t < t0 + kGenericPer && t < n_tiles; t++) {
+        if (!W.tile_flag[t]) continue;   // uniform over the workgroup
+        emit_tile_generic(W, A, t, n_tiles, docinc, tokpre, tmp64, q_out, q_item, &q_n);
+        __syncthreads();
+    }
+}
+
 
 // ---- decode (tokenizer.go:339-354): ids -> bytes, out-of-range ids skipped ------------------------------
 __global__ void decode_len_kernel(const uint32_t* tok_off, int n_tokens, const int32_t* ids, const uint64_t* id_off,
@@ -1571,13 +1819,16 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         L3_LAUNCH_CHECK();
         L3_EV(kEvSlow);
         const uint64_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
-        hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks), dim3(256), 0, stream, W, n_tiles);
+        hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks), dim3(kScanBlock), 0, stream, W, n_tiles);
         L3_LAUNCH_CHECK();
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, W, A, n_blocks);
         L3_LAUNCH_CHECK();
         L3_EV(kEvScan);
     }
     hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)n_tiles), dim3(kTileThreads), 0, stream, W, A);
+    L3_LAUNCH_CHECK();
+    hipLaunchKernelGGL(emit_generic_kernel, dim3((uint32_t)((n_tiles + kGenericPer - 1) / kGenericPer)), dim3(kTileThreads), 0,
+                       stream, W, A, n_tiles);
     L3_LAUNCH_CHECK();
     L3_EV(kEvEmit);
     return hipSuccess;

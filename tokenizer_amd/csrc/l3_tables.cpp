@@ -215,7 +215,7 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
             bool placed = false;
             for (int kick = 0; kick < 1000 && !placed; kick++) {
                 uint32_t b[2];
-                pair_hash2(item >> 24, T.pair_log2, &b[0], &b[1]);
+                pair_hash2((uint32_t)(item >> 41), (uint32_t)((item >> 24) & 0x1FFFFu), T.pair_log2, &b[0], &b[1]);
                 for (int k = 0; k < 4 && !placed; k++) {
                     uint64_t& slot = T.pair_buckets[b[k >> 1]].s[k & 1];
                     if (slot == kPairEmpty) { slot = item; placed = true; }
