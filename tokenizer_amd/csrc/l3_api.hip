@@ -43,6 +43,8 @@ struct l3_ctx {
     HostTables H;
     Tables T{};
     DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes;
+    bool clear_pending = false;       // a clear of w_status is queued on clear_stream
+    hipStream_t clear_stream = nullptr;
     DevBuf w_stream, w_items, w_extra, w_base, w_pre, w_flag, w_doc0, w_docitem, w_slow, w_miss, w_missres, w_pool, w_scratch, w_status;
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
     uint64_t slow_cap = 0, miss_shard_cap = 0, pool_cap = 0, scratch_cap = 0;
@@ -114,7 +116,10 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     HIPCHK(c, c->w_flag.ensure(n_tiles * 4));
     HIPCHK(c, c->w_doc0.ensure((n_tiles + 1) * 4));
     HIPCHK(c, c->w_docitem.ensure((n_docs + 1) * 4));
-    HIPCHK(c, c->w_status.ensure(sizeof(Status)));
+    if (!c->w_status.p) {
+        HIPCHK(c, c->w_status.ensure(sizeof(Status)));
+        HIPCHK(c, hipMemset(c->w_status.p, 0, sizeof(Status)));
+    }
     uint64_t slow_min = n_bytes / 256 + 1024, miss_min = n_bytes / 64 / kMissShards + 256, pool_min = n_bytes / 8 + 4096,
              scratch_min = 16ull << 20;
     if (c->slow_cap < slow_min) c->slow_cap = slow_min;
@@ -161,11 +166,16 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         Workspace W{};
         int rc = ensure_workspace(c, A.n_bytes, A.n_docs, W);
         if (rc) return rc;
-        HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream));
-        HIPCHK(c, hipMemsetAsync(W.tile_extra, 0, n_tiles * 4, stream));
+        // W.status is all zero here: cleared when the context made it and again after every read-back below, so the
+        // clear runs while the host is busy between two calls instead of in front of the kernels
+        if (c->clear_pending && c->clear_stream != stream) HIPCHK(c, hipStreamSynchronize(c->clear_stream));
+        c->clear_pending = false;
         HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false));
         HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
+        HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream));
+        c->clear_pending = true;
+        c->clear_stream = stream;
         const Status st = *c->h_status;
         if (st.flags & kBadOffsets) {
             c->err = "doc_off must start at 0, be ascending and end at n_bytes";

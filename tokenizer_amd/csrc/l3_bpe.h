@@ -59,19 +59,22 @@ L3_HD void pair_prio2(const Tables& t, uint32_t a0, uint32_t b0, uint32_t a1, ui
 #endif
 }
 
-// Whole-string probe for a string of <= 12 bytes given as three zero-padded words: four independent slot loads.
+// Whole-string probe for a string of <= 12 bytes given as three zero-padded words.  First-choice bucket first; the
+// second load is issued only by the lanes that did not find their string there (tokens that lost their first
+// choice at build time, and strings that are no token).
 L3_HD int32_t vocab_lookup_short(const Tables& t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len) {
     uint32_t b1, b2;
     vocab_hash_short2(w0, w1, w2, len, t.vocab_log2, &b1, &b2);
-    const VocabSlot s0 = t.vocab_slots[2u * b1], s1 = t.vocab_slots[2u * b1 + 1u], s2 = t.vocab_slots[2u * b2],
-                    s3 = t.vocab_slots[2u * b2 + 1u];
     const uint32_t tag_lo = len << 17;
-    int32_t r = -1;
-    if ((s0.w[3] & ~0x1FFFFu) == tag_lo && s0.w[0] == w0 && s0.w[1] == w1 && s0.w[2] == w2) r = (int32_t)(s0.w[3] & 0x1FFFFu);
-    if ((s1.w[3] & ~0x1FFFFu) == tag_lo && s1.w[0] == w0 && s1.w[1] == w1 && s1.w[2] == w2) r = (int32_t)(s1.w[3] & 0x1FFFFu);
-    if ((s2.w[3] & ~0x1FFFFu) == tag_lo && s2.w[0] == w0 && s2.w[1] == w1 && s2.w[2] == w2) r = (int32_t)(s2.w[3] & 0x1FFFFu);
-    if ((s3.w[3] & ~0x1FFFFu) == tag_lo && s3.w[0] == w0 && s3.w[1] == w1 && s3.w[2] == w2) r = (int32_t)(s3.w[3] & 0x1FFFFu);
-    return r;
+    const VocabSlot s0 = t.vocab_slots[b1];
+#ifdef L3_VOCAB_PARALLEL
+    const VocabSlot sp = t.vocab_slots[b2];
+    if ((sp.w[3] & ~0x1FFFFu) == tag_lo && sp.w[0] == w0 && sp.w[1] == w1 && sp.w[2] == w2) return (int32_t)(sp.w[3] & 0x1FFFFu);
+#endif
+    if ((s0.w[3] & ~0x1FFFFu) == tag_lo && s0.w[0] == w0 && s0.w[1] == w1 && s0.w[2] == w2) return (int32_t)(s0.w[3] & 0x1FFFFu);
+    const VocabSlot s1 = t.vocab_slots[b2];
+    if ((s1.w[3] & ~0x1FFFFu) == tag_lo && s1.w[0] == w0 && s1.w[1] == w1 && s1.w[2] == w2) return (int32_t)(s1.w[3] & 0x1FFFFu);
+    return -1;
 }
 
 // Whole-string lookup by words.  `getw(i)` returns little-endian word i of the (already expanded) pre-token,
@@ -85,8 +88,8 @@ L3_HD int32_t vocab_lookup_words(const Tables& t, GetW getw, uint32_t len) {
     for (uint32_t i = 0; i < nw; i++) strhash_add(h, getw(i));
     uint32_t b[2];
     strhash_buckets(h, len, t.vocab_log2, &b[0], &b[1]);
-    for (int k = 0; k < 4; k++) {
-        const VocabSlot v = t.vocab_slots[2u * b[k >> 1] + (uint32_t)(k & 1)];
+    for (int k = 0; k < 2; k++) {
+        const VocabSlot v = t.vocab_slots[b[k]];
         if (v.w[3] == kVocabEmpty || (v.w[3] >> 17) != len || v.w[0] != h.h2) continue;
         const uint32_t* blob = t.vocab_blob + v.w[1];
         bool eq = true;

@@ -55,7 +55,7 @@ L3_HD void pair_hash2(uint32_t a, uint32_t b, uint32_t log2_buckets, uint32_t* b
     *b2 = mul24(y, 0x7FEB35u) >> (32 - log2_buckets);
 }
 
-// ---- vocabulary table: raw token bytes -> id, two-choice (cuckoo) hashing, 32-byte buckets of two slots --
+// ---- vocabulary table: raw token bytes -> id, two-choice (cuckoo) hashing, one 16-byte slot per bucket ----
 // slot: w[3] = id | len << 17 ; len <= 12: w[0..2] hold the bytes (little endian, zero padded);
 // len > 12: w[0] = second hash, w[1] = WORD offset of the bytes in the blob (every entry starts on a
 // 4-byte boundary, its last word zero padded), w[2] = 0.  empty: w[3] = 0xFFFFFFFF.
@@ -67,17 +67,19 @@ L3_HD uint32_t mix32(uint32_t x) {
     return x;
 }
 L3_HD uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
-// short strings (<= 12 bytes) hash their three little-endian words directly (four multiplies in all)
+// short strings (<= 12 bytes): two independent hashes of their three little-endian words, built from full-rate
+// 24-bit multiplies.  Each word is folded to 24 bits first, differently for the two hashes, so that no pair of
+// words collides in both.
 L3_HD void vocab_hash_short2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len, uint32_t log2_buckets, uint32_t* b1,
                              uint32_t* b2) {
-    uint32_t x = w0 * 0x9E3779B1u;
-    x = (rotl32(x, 15) ^ w1) * 0x85EBCA6Bu;
-    x = rotl32(x, 13) ^ w2 ^ (len << 27);
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
-    uint32_t z = x * 0x846CA68Bu;
-    z ^= z >> 16;
-    *b1 = x >> (32 - log2_buckets);
-    *b2 = z >> (32 - log2_buckets);
+    uint32_t x = mul24(w0 ^ (w0 >> 13), 0x9E3779u) + mul24(w1 ^ (w1 >> 13), 0x85EBCBu) + mul24(w2 ^ (w2 >> 13), 0xC2B2AFu) +
+                 mul24(len, 0x27D4EBu);
+    uint32_t y = mul24(w0 ^ (w0 >> 9), 0x7FEB35u) + mul24(w1 ^ (w1 >> 9), 0x846CA7u) + mul24(w2 ^ (w2 >> 9), 0xD6E8FFu) +
+                 mul24(len, 0x165667u);
+    x ^= x >> 15;
+    y ^= y >> 14;
+    *b1 = mul24(x, 0xB5297Bu) >> (32 - log2_buckets);
+    *b2 = mul24(y, 0x68E31Du) >> (32 - log2_buckets);
 }
 // longer strings: two running hashes over the little-endian words of the (expanded) pre-token, the last
 // word zero padded
@@ -104,7 +106,7 @@ struct Tables {
     const uint8_t* byte_tok;      // [256] token id of each single byte (ids 0..255)
     const uint32_t* bytepair;     // [65536] prio of (byte a, byte b) indexed a<<8|b, kNoPrio if no rule
     const PairBucket* pair_buckets;  // [1 << pair_log2]
-    const VocabSlot* vocab_slots; // [2 << vocab_log2]: bucket b = slots 2b, 2b+1
+    const VocabSlot* vocab_slots; // [1 << vocab_log2]
     const uint32_t* vocab_blob;   // raw bytes of tokens longer than kVocabInline, as zero-padded words
     const int32_t* special_id;    // [256] canonical special index -> token id (0 = not a token)
     uint32_t pair_log2;

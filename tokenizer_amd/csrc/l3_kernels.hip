@@ -233,22 +233,20 @@ __device__ uint32_t digits_before_global(const uint8_t* text, int64_t seg_lo, in
     return total;
 }
 
-// ---- validate + first document per tile -----------------------------------------------------------
-__global__ void validate_kernel(Workspace W, EncodeArgs A) {
-    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d > A.n_docs) return;
-    uint64_t off = A.doc_off[d];
-    uint64_t prev = d ? A.doc_off[d - 1] : 0;
-    bool bad = (d == 0 && off != 0) || (d == A.n_docs && off != A.n_bytes) || off < prev || off > A.n_bytes;
-    if (bad) atomicOr(&W.status->flags, kBadOffsets);
-}
-
+// ---- validate the offsets, first document per tile, clear the per-tile counters ------------------------
+// One thread per document offset.  A thread whose own offset is in order writes the first-document entries of the
+// tiles that start in (previous offset, offset]; the clamp keeps every write in bounds whatever the other offsets
+// are, and all later kernels return at once when kBadOffsets is set.
 __global__ void docs_kernel(Workspace W, EncodeArgs A, uint64_t n_tiles) {
-    if (W.status->flags & kBadOffsets) return;
-    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t t = gid; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) W.tile_extra[t] = 0;
+    const uint64_t d = gid;
     if (d > A.n_docs) return;
-    uint64_t off = A.doc_off[d];
-    uint64_t t_first = d ? A.doc_off[d - 1] / kTile + 1 : 0;   // tiles whose start lies in (prev, off]
+    const uint64_t off = A.doc_off[d];
+    const uint64_t prev = d ? A.doc_off[d - 1] : 0;
+    const bool bad = (d == 0 && off != 0) || (d == A.n_docs && off != A.n_bytes) || off < prev || off > A.n_bytes;
+    if (bad) { atomicOr(&W.status->flags, kBadOffsets); return; }
+    const uint64_t t_first = d ? prev / kTile + 1 : 0;   // tiles whose start lies in (prev, off]
     uint64_t t_last = off / kTile;
     if (t_last > n_tiles - 1) t_last = n_tiles - 1;
     for (uint64_t t = t_first; t <= t_last; t++) W.tile_doc0[t] = (uint32_t)d;
@@ -268,15 +266,17 @@ enum { B_ST = 0, B_SPS, B_INV, B_DS, B_LIVE, B_RS = B_LIVE, B_L, B_N, B_NL, B_SP
        B_SPB, B_SPE, B_CONTN, B_COUNT };
 
 constexpr int kResCap = (B_COUNT - B_LIVE) * (kWords + 2) * 2;  // stream items staged in LDS (the rest goes straight to HBM)
+constexpr int kRareCap = 512;
 struct TileLds {
     uint8_t b[kRegion + 16];
     u64 bm[B_COUNT][kWords + 2];
     uint16_t list[kTile];      // compacted own pre-token starts (region-local offsets)
     uint16_t wpre[kWords + 1]; // own pre-token starts before each mask word
+    uint16_t rare[kRareCap];   // list index k of the pre-tokens left to the second lookup pass
 };
 constexpr int kListPer = 16;
 static_assert(kListPer * kTileThreads >= kTile && 64 % kListPer == 0 && kBack % kListPer == 0, "list compaction geometry");
-enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NMISS, TV_NSLOW, TV_MISS0, TV_SLOW0, TV_COUNT = 8 };
+enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NMISS, TV_NSLOW, TV_MISS0, TV_SLOW0, TV_NRARE, TV_COUNT = 8 };
 
 struct TileSrc {  // byte source over the tile's LDS image, LOCAL coordinates [0, n)
     const TileLds* R;
@@ -491,6 +491,21 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
 #define L3_DBG(flags, bit) false
 #endif
 
+// measurement only (tools/build_variant.sh NAME "-DL3_TILE_STOP=n"): leave the tile kernel after phase n (1 load +
+// classify, 2 start bits, 3 list, 4 vocabulary probes) with an empty but well-formed tile, so that the later kernels
+// stay in bounds
+#ifdef L3_TILE_STOP
+#define L3_STOP_AFTER(nphase)                                                                                  \
+    if (L3_TILE_STOP == (nphase)) {                                                                            \
+        if (tid == 0) W.tile_items[tile] = 0;                                                                  \
+        const uint64_t de_ = tile + 1 == gridDim.x ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];           \
+        for (uint64_t d = (uint64_t)d0 + tid; d < de_; d += kTileThreads) W.doc_item[d] = 0;                   \
+        return;                                                                                                \
+    }
+#else
+#define L3_STOP_AFTER(nphase)
+#endif
+
 #ifndef L3_TILE_OCC
 #define L3_TILE_OCC 6
 #endif
@@ -516,7 +531,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     for (int i = tid; i < kWords + 2; i += kTileThreads) {
         R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0; R.bm[B_CE2][i] = 0; R.bm[B_CE3][i] = 0;
     }
-    if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; }
+    if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; vars[TV_NRARE] = 0; }
     const int c0 = tid * 16;            // region bytes [c0, c0 + 16) are classified by this thread
     const bool cls_thread = tid < kRegion / 16;
     uint32_t xw[4] = {0, 0, 0, 0};
@@ -632,6 +647,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         h = reinterpret_cast<uint16_t*>(R.bm[B_NX]); h[tid] = (uint16_t)m_nx;
     }
     __syncthreads();
+    L3_STOP_AFTER(1)
 
     // -- start-of-pre-token bits (one wave), digit runs that need more context than the halo holds
     if (wave == 0) {
@@ -700,6 +716,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     }
     const uint32_t n_pre = (uint32_t)vars[TV_NPRE];
     const u64* ST = R.bm[B_ST];
+    L3_STOP_AFTER(2)
 
     // -- compacted list of own pre-token starts (kListPer byte positions per thread; own_lo is 0 or kBack, so a
     //    thread's positions never straddle a 64-bit mask word)
@@ -726,34 +743,46 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         }
     }
     __syncthreads();
+    L3_STOP_AFTER(3)
 
     int32_t* res = reinterpret_cast<int32_t*>(&R.bm[B_LIVE][0]);
     int32_t* out0 = W.stream + tile * (uint64_t)kTileCap;
     // -- per pre-token: special id / whole-string vocabulary probe (bpe.go:27-33) / defer.  One stream item each.
+    //    Two passes over the same code: the first does the common case (up to 12 valid bytes, no special token) and
+    //    only lists the others; the second does the listed ones, densely packed.  Otherwise one rare pre-token
+    //    among the 64 of a wave iteration makes the whole wave walk the long path (six iterations in ten on C2).
 #pragma unroll 1
-    for (uint32_t k = tid; k < n_pre; k += kTileThreads) {
-        const int s = R.list[k];
-        int32_t item;
-        if ((R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull) {
-            int canon = 0;
-            special_match(src, s, &canon);
-            item = T.special_id[canon];
-        } else {
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t n_iter = pass == 0 ? n_pre : ((uint32_t)vars[TV_NRARE] < (uint32_t)kRareCap ? (uint32_t)vars[TV_NRARE] : (uint32_t)kRareCap);
+#pragma unroll 1
+        for (uint32_t it = tid; it < n_iter; it += kTileThreads) {
+            const uint32_t k = pass == 0 ? it : (uint32_t)R.rare[it];
+            const int s = R.list[k];
+            const bool special = (R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull;
             int e = find_next_bit64(ST, s + 1, eval_hi);
             if (e < 0 && hard) e = n;
-            int32_t id = -1;
-            bool inval = false;
             const int len = e - s;
-            if (e >= 0) {
-                inval = any_bit_in(R.bm[B_INV], s, e);
-                if (L3_DBG(A.flags, 0x200u)) id = 1;
-                else if (!inval && len <= kMaxTokenBytes) {
+            const bool inval = e >= 0 && any_bit_in(R.bm[B_INV], s, e);
+            const bool rare = special || e < 0 || inval || len > kVocabInline;
+            if (pass == 0 && rare) {
+                const uint32_t idx = (uint32_t)atomicAdd(&vars[TV_NRARE], 1);
+                if (idx < (uint32_t)kRareCap) { R.rare[idx] = (uint16_t)k; continue; }
+                // list full: done here and now
+            }
+            int32_t item;
+            if (special) {
+                int canon = 0;
+                special_match(src, s, &canon);
+                item = T.special_id[canon];
+            } else {
+                int32_t id = -1;
+                if (e >= 0 && !inval && len <= kMaxTokenBytes && !L3_DBG(A.flags, 0x200u)) {
                     // little-endian words of the pre-token straight from the LDS image (unaligned start)
                     const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
                     const uint32_t sh = (uint32_t)(s & 3) * 8u;
                     const uint32_t nw = ((uint32_t)len + 3u) >> 2;
                     const uint32_t tail = (len & 3) ? (1u << ((len & 3) * 8)) - 1u : 0xFFFFFFFFu;
-                    if (len <= kVocabInline) {
+                    if (!rare) {
                         const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
                         uint32_t w0 = __funnelshift_r(x0, x1, sh), w1 = __funnelshift_r(x1, x2, sh), w2 = __funnelshift_r(x2, x3, sh);
                         if (nw == 1) { w0 &= tail; w1 = 0; w2 = 0; }
@@ -767,17 +796,20 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                             return i + 1 == nw ? x & tail : x;
                         }, (uint32_t)len);
                     }
+                } else if (L3_DBG(A.flags, 0x200u)) {
+                    id = 1;
                 }
+                if (id >= 0) item = id;
+                else if (e >= 0 && !inval && len <= kLaneMax) item = -2 - (int32_t)atomicAdd(&vars[TV_NMISS], 1);  // local ordinal
+                else item = -2 - (int32_t)(kSlowBase + (uint32_t)atomicAdd(&vars[TV_NSLOW], 1));
             }
-            if (id >= 0) item = id;
-            else if (e >= 0 && !inval && len <= kLaneMax) item = -2 - (int32_t)atomicAdd(&vars[TV_NMISS], 1);  // local ordinal
-            else item = -2 - (int32_t)(kSlowBase + (uint32_t)atomicAdd(&vars[TV_NSLOW], 1));
+            // deferred: the local ordinal for now, replaced below by the global entry index.  Staged in LDS (the bitmap
+            // rows that are dead by now); text of one- and two-byte pre-tokens can exceed it and goes straight to HBM
+            if (k < (uint32_t)kResCap) res[k] = item; else out0[k] = item;
         }
-        // deferred: the local ordinal for now, replaced below by the global entry index.  Staged in LDS (the bitmap
-        // rows that are dead by now); text of one- and two-byte pre-tokens can exceed it and goes straight to HBM
-        if (k < (uint32_t)kResCap) res[k] = item; else out0[k] = item;
+        __syncthreads();
     }
-    __syncthreads();
+    L3_STOP_AFTER(4)
     const uint32_t shard = (uint32_t)(tile % kMissShards);
     if (tid == 0) {
         const uint32_t nm = (uint32_t)vars[TV_NMISS], ns = (uint32_t)vars[TV_NSLOW];
@@ -1796,8 +1828,6 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
     if (!emit_only) {
         L3_EV(kEvStart);
         const uint32_t dblocks = (uint32_t)((A.n_docs + 1 + 255) / 256);
-        hipLaunchKernelGGL(validate_kernel, dim3(dblocks), dim3(256), 0, stream, W, A);
-        L3_LAUNCH_CHECK();
         hipLaunchKernelGGL(docs_kernel, dim3(dblocks), dim3(256), 0, stream, W, A, n_tiles);
         L3_LAUNCH_CHECK();
         L3_EV(kEvDocs);

@@ -232,7 +232,7 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
         if (T.pair_log2 > 24) { T.error = "pair table placement failed"; return false; }
     }
 
-    // ---- whole-string vocabulary table (bpe.go:27-33 looks the whole pre-token up first): cuckoo as well
+    // ---- whole-string vocabulary table (bpe.go:27-33 looks the whole pre-token up first): two-choice cuckoo as well
     T.vocab_blob.clear();
     std::vector<VocabSlot> items;
     items.reserve(by_bytes.size());
@@ -268,23 +268,26 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
             strhash_buckets(h, len, T.vocab_log2, &b[0], &b[1]);
         }
     };
+    // one slot per bucket, load factor <= 1/4; tokens are placed in id order (roughly by falling frequency) and take
+    // their first-choice bucket when it is free, so the probe of a frequent token ends after one 16-byte load
     for (T.vocab_log2 = 14;; T.vocab_log2++) {
-        if ((2ull << T.vocab_log2) < items.size() * 2) continue;  // load factor <= 1/2
-        T.vocab_slots.assign(2ull << T.vocab_log2, VocabSlot{{0, 0, 0, kVocabEmpty}});
+        if ((1ull << T.vocab_log2) < items.size() * 4) continue;
+        T.vocab_slots.assign(1ull << T.vocab_log2, VocabSlot{{0, 0, 0, kVocabEmpty}});
         bool ok = true;
         for (VocabSlot item : items) {
             bool placed = false;
+            uint32_t from = 0xFFFFFFFFu;  // bucket the item in hand was evicted from
             for (int kick = 0; kick < 1000 && !placed; kick++) {
                 uint32_t b[2];
                 vbuckets(item, b);
-                for (int k = 0; k < 4 && !placed; k++) {
-                    VocabSlot& slot = T.vocab_slots[2ull * b[k >> 1] + (k & 1)];
+                for (int k = 0; k < 2 && !placed; k++) {
+                    VocabSlot& slot = T.vocab_slots[b[k]];
                     if (slot.w[3] == kVocabEmpty) { slot = item; placed = true; }
                 }
                 if (!placed) {
-                    uint64_t rr = next_rand();
-                    VocabSlot& slot = T.vocab_slots[2ull * b[rr & 1] + ((rr >> 1) & 1)];
-                    std::swap(slot, item);
+                    uint32_t victim = b[0] == from ? b[1] : (b[1] == from ? b[0] : b[next_rand() & 1]);
+                    std::swap(T.vocab_slots[victim], item);
+                    from = victim;
                 }
             }
             if (!placed) { ok = false; break; }
