@@ -130,6 +130,37 @@ int64_t l3t_bpe(void* hp, const uint8_t* bytes, int64_t n, int32_t* out, int64_t
     return k;
 }
 
+// Probe statistics of the greedy merge of one pre-token: out = [probes, probes whose operands both occur on that
+// side of some rule (tok_flags), probes that find a rule, merges]
+void l3t_probe_stats(void* hp, const uint8_t* bytes, int64_t n, int64_t* out) {
+    Handle* h = (Handle*)hp;
+    const Tables& T = h->T;
+    std::vector<int32_t> sym((size_t)n);
+    std::vector<uint32_t> pr((size_t)n, kNoPrio);
+    for (int64_t i = 0; i < n; i++) sym[i] = T.byte_tok[bytes[i]];
+    for (int64_t i = 0; i + 1 < n; i++) pr[i] = T.bytepair[((uint32_t)bytes[i] << 8) | bytes[i + 1]];
+    auto probe = [&](uint32_t a, uint32_t b) {
+        out[0]++;
+        if ((h->H.tok_flags[a] & 1) && (h->H.tok_flags[b] & 2)) out[1]++;
+        uint32_t p = pair_prio(T, a, b);
+        if (p != kNoPrio) out[2]++;
+        return p;
+    };
+    for (;;) {
+        uint32_t best = kNoPrio; int bp = -1;
+        for (int p = 0; p < (int)n; p++) if (pr[p] < best) { best = pr[p]; bp = p; }
+        if (bp < 0) break;
+        out[3]++;
+        int q = bp + 1; while (sym[q] < 0) q++;
+        int r = q + 1; while (r < (int)n && sym[r] < 0) r++;
+        int l = bp - 1; while (l >= 0 && sym[l] < 0) l--;
+        uint32_t m = prio_merged_id(best);
+        sym[bp] = (int32_t)m; sym[q] = -1; pr[q] = kNoPrio;
+        pr[bp] = r < (int)n ? probe(m, (uint32_t)sym[r]) : kNoPrio;
+        if (l >= 0) pr[l] = probe((uint32_t)sym[l], m);
+    }
+}
+
 // Sequential emulation of the ROUND-BASED merge of the slow kernel (l3_kernels.hip merge_rounds): same set S,
 // same beta / theta rule, same compaction; lets the CPU suite fuzz the algorithm against the oracle.
 // Returns the number of tokens; *rounds receives the number of rounds it took.

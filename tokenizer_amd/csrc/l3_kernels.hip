@@ -1006,8 +1006,7 @@ __device__ __forceinline__ void lane_finish(const Workspace& W, const uint32_t* 
         if (lane_id() == 63) wbase = atomicAdd(&W.status->pool_used, (unsigned long long)wtot);
         wbase = __shfl(wbase, 63, 64);
     }
-    if (!act) return;
-    if (need) {
+    if (act && need) {
         const unsigned long long dst = wbase + inc - need;
         if (dst + n_out <= W.pool_cap) {
             uint32_t p = 0, k = 0;
@@ -1021,8 +1020,28 @@ __device__ __forceinline__ void lane_finish(const Workspace& W, const uint32_t* 
         }
         inl = dst;
     }
-    W.miss_res[ei] = (inl << 8) | n_out;
-    if (n_out > 1) atomicAdd(&W.tile_extra[tile], n_out - 1);
+    if (act) W.miss_res[ei] = (inl << 8) | n_out;
+    // tile_extra: neighbouring lanes mostly hold pre-tokens of one tile, so the additions of a run of lanes with the
+    // same tile are summed in the wave first (segmented scan) and its last lane issues one atomic
+    const uint32_t key = act ? tile : 0xFFFFFFFFu;
+    uint32_t sum = (act && n_out > 1) ? n_out - 1 : 0u;
+    const uint32_t prev_key = __shfl_up(key, 1, 64);
+    const bool head = lane_id() == 0 || prev_key != key;
+    // distance to the head of the run: max-scan of the head positions
+    uint32_t hp = head ? (uint32_t)lane_id() : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(hp, d, 64);
+        if (lane_id() >= d) hp = o > hp ? o : hp;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(sum, d, 64);
+        if (lane_id() >= d && (uint32_t)(lane_id() - d) >= hp) sum += o;
+    }
+    const uint32_t next_key = __shfl_down(key, 1, 64);
+    const bool tail = lane_id() == 63 || next_key != key;
+    if (act && tail && sum) atomicAdd(&W.tile_extra[tile], sum);
 }
 
 __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspace W, EncodeArgs A) {

@@ -197,6 +197,8 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
     T.n_merges = (int)rules.size();
 
     // direct byte-pair table
+    T.tok_flags.assign((size_t)T.n_tokens, 0);
+    for (const Rule& r : rules) { T.tok_flags[r.a] |= 1; T.tok_flags[r.b] |= 2; }
     T.bytepair.assign(65536, kNoPrio);
     uint8_t tok_byte[256];  // id -> byte for ids 0..255
     for (int b = 0; b < 256; b++) tok_byte[T.byte_tok[b]] = (uint8_t)b;

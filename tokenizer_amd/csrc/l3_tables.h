@@ -17,6 +17,7 @@ struct HostTables {
     std::vector<uint8_t> cls_blocks;
     uint8_t byte_tok[256];
     std::vector<uint32_t> bytepair;
+    std::vector<uint8_t> tok_flags;   // per token id: bit0 = left operand of some merge rule, bit1 = right operand
     std::vector<PairBucket> pair_buckets;  // 1 << pair_log2 buckets
     uint32_t pair_log2 = 0;
     std::vector<VocabSlot> vocab_slots;
