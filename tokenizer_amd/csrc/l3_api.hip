@@ -47,7 +47,7 @@ struct l3_ctx {
     hipStream_t clear_stream = nullptr;
     DevBuf w_stream, w_items, w_extra, w_base, w_pre, w_flag, w_doc0, w_docitem, w_slow, w_miss, w_missres, w_pool, w_scratch, w_status;
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
-    uint64_t slow_cap = 0, miss_shard_cap = 0, pool_cap = 0, scratch_cap = 0;
+    uint64_t slow_cap = 0, miss_shard_cap = 0, mpool_shard_cap = 0, pool_cap = 0, scratch_cap = 0;
     Status* h_status = nullptr;          // pinned
     unsigned long long* h_total = nullptr;  // pinned
     hipStream_t stream = nullptr;
@@ -125,11 +125,13 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     if (c->slow_cap < slow_min) c->slow_cap = slow_min;
     if (c->miss_shard_cap < miss_min) c->miss_shard_cap = miss_min;
     if (c->pool_cap < pool_min) c->pool_cap = pool_min;
+    const uint64_t mpool_min = n_bytes / 16 / kMissShards + 1024;
+    if (c->mpool_shard_cap < mpool_min) c->mpool_shard_cap = mpool_min;
     if (c->scratch_cap < scratch_min) c->scratch_cap = scratch_min;
     HIPCHK(c, c->w_slow.ensure(c->slow_cap * sizeof(SlowEntry)));
     HIPCHK(c, c->w_miss.ensure(c->miss_shard_cap * kMissShards * sizeof(MissIn)));
     HIPCHK(c, c->w_missres.ensure(c->miss_shard_cap * kMissShards * sizeof(uint64_t)));
-    HIPCHK(c, c->w_pool.ensure(c->pool_cap * sizeof(int32_t)));
+    HIPCHK(c, c->w_pool.ensure((c->mpool_shard_cap * kMissShards + c->pool_cap) * sizeof(int32_t)));
     HIPCHK(c, c->w_scratch.ensure(c->scratch_cap));
     W.stream = c->w_stream.as<int32_t>();
     W.tile_items = c->w_items.as<uint32_t>();
@@ -148,6 +150,7 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     W.status = c->w_status.as<Status>();
     W.slow_cap = c->slow_cap;
     W.pool_cap = c->pool_cap;
+    W.mpool_shard_cap = c->mpool_shard_cap;
     W.scratch_cap = c->scratch_cap;
     return L3_OK;
 }
@@ -183,13 +186,19 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         }
         bool grow = false;
         if (st.flags & kOvfSlow) { c->slow_cap = (uint64_t)st.slow_count + st.slow_count / 4 + 1024; grow = true; }
-        uint64_t miss_total = 0, miss_max = 0;
+        uint64_t miss_total = 0, miss_max = 0, mpool_max = 0, mpool_total = 0;
         for (int i = 0; i < kMissShards; i++) {
-            miss_total += st.miss_count[i];
-            if (st.miss_count[i] > miss_max) miss_max = st.miss_count[i];
+            miss_total += st.shard[i].miss_count;
+            if (st.shard[i].miss_count > miss_max) miss_max = st.shard[i].miss_count;
+            if (st.shard[i].pool_used > mpool_max) mpool_max = st.shard[i].pool_used;
+            mpool_total += st.shard[i].pool_used;
         }
         if (st.flags & kOvfMiss) { c->miss_shard_cap = miss_max + miss_max / 4 + 256; grow = true; }
-        if (st.flags & kOvfPool) { c->pool_cap = st.pool_used + st.pool_used / 4 + 4096; grow = true; }
+        if (st.flags & kOvfPool) {
+            if (st.pool_used > c->pool_cap) c->pool_cap = st.pool_used + st.pool_used / 4 + 4096;
+            if (mpool_max > c->mpool_shard_cap) c->mpool_shard_cap = mpool_max + mpool_max / 4 + 1024;
+            grow = true;
+        }
         if (st.flags & kOvfScratch) { c->scratch_cap = st.scratch_used + st.scratch_used / 4 + (1ull << 20); grow = true; }
         if (grow) {
             if (attempt >= 8) { c->err = "workspace did not converge"; return L3_E_HIP; }
@@ -208,7 +217,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         }
         c->counters[0] = n_tiles;
         c->counters[1] = st.slow_count;
-        c->counters[2] = st.pool_used;
+        c->counters[2] = st.pool_used + mpool_total;
         c->counters[3] = st.scratch_used;
         c->counters[5] = miss_total;
         *n_tok = st.total_tokens;

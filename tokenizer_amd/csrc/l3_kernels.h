@@ -59,9 +59,13 @@ struct Status {
     unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
     unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the scan)
     unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)
-    // short entries appended so far per shard (may exceed the shard capacity: overflow).  One counter per
-    // shard (shard = tile % kMissShards) keeps ~10^4 tiles from serialising on one atomic word.
-    uint32_t miss_count[64];
+    // Per shard (shard = tile % kMissShards), each on a cache line of its own: atomics that return a value and
+    // share an address (or a line) queue up behind each other, ~10^4 of them cost tens of microseconds.
+    struct alignas(128) Shard {
+        uint32_t miss_count;            // short entries appended so far (may exceed the shard capacity: overflow)
+        uint32_t pad;
+        unsigned long long pool_used;   // tokens reserved in the shard's part of the pool (may exceed mpool_shard_cap)
+    } shard[64];
 };
 constexpr int kMissShards = 64;
 // a short deferred pre-token (input of merge_kernel).  Its result is one word of miss_res: bits 0..7 = n tokens;
@@ -86,10 +90,11 @@ struct Workspace {
     SlowEntry* slow;        // [slow_cap]
     MissIn* miss_in;        // [kMissShards * miss_shard_cap]
     uint64_t* miss_res;     // [kMissShards * miss_shard_cap]
-    int32_t* pool;          // [pool_cap] tokens of slow pre-tokens
+    int32_t* pool;          // [kMissShards * mpool_shard_cap + pool_cap]: results of more than kMissInline tokens of the
+                            // merge kernel, one part per shard, then the tokens of the slow pre-tokens
     uint8_t* scratch;       // [scratch_cap] symbol arrays of pre-tokens too long for LDS
     Status* status;
-    uint64_t slow_cap, miss_shard_cap, pool_cap, scratch_cap;
+    uint64_t slow_cap, miss_shard_cap, mpool_shard_cap, pool_cap, scratch_cap;
 };
 
 struct EncodeArgs {

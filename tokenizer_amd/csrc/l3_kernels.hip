@@ -506,6 +506,9 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
 #define L3_STOP_AFTER(nphase)
 #endif
 
+#ifndef L3_MERGE_STOP
+#define L3_MERGE_STOP 0
+#endif
 #ifndef L3_TILE_OCC
 #define L3_TILE_OCC 6
 #endif
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     const uint32_t shard = (uint32_t)(tile % kMissShards);
     if (tid == 0) {
         const uint32_t nm = (uint32_t)vars[TV_NMISS], ns = (uint32_t)vars[TV_NSLOW];
-        uint32_t m0 = nm ? atomicAdd(&W.status->miss_count[shard], nm) : 0u;
+        uint32_t m0 = nm ? atomicAdd(&W.status->shard[shard].miss_count, nm) : 0u;
         uint32_t s0 = ns ? atomicAdd(&W.status->slow_count, ns) : 0u;
         if (nm && (uint64_t)m0 + nm > W.miss_shard_cap) atomicOr(&W.status->flags, kOvfMiss);
         if (ns && (uint64_t)s0 + ns > W.slow_cap) atomicOr(&W.status->flags, kOvfSlow);
@@ -986,7 +989,8 @@ __device__ __forceinline__ void lane_merge(const Tables& T, uint32_t* sy, uint32
 
 // Stores the result of a finished slot: miss_res word (tokens inline or in the pool), tile_extra.  All lanes of
 // the wave call it together (`act`: this lane has a result); pool space is one atomic per wave.
-__device__ __forceinline__ void lane_finish(const Workspace& W, const uint32_t* sy, bool act, uint64_t ei, uint32_t tile) {
+__device__ __forceinline__ void lane_finish(const Workspace& W, const uint32_t* sy, bool act, uint64_t ei, uint32_t tile,
+                                            uint32_t shard) {
     uint32_t n_out = 0;
     uint64_t inl = 0;
     if (act) {
@@ -1003,12 +1007,13 @@ __device__ __forceinline__ void lane_finish(const Workspace& W, const uint32_t* 
     const uint32_t wtot = __shfl(inc, 63, 64);
     unsigned long long wbase = 0;
     if (wtot) {   // uniform over the wave
-        if (lane_id() == 63) wbase = atomicAdd(&W.status->pool_used, (unsigned long long)wtot);
+        if (lane_id() == 63) wbase = atomicAdd(&W.status->shard[shard].pool_used, (unsigned long long)wtot);
         wbase = __shfl(wbase, 63, 64);
     }
     if (act && need) {
-        const unsigned long long dst = wbase + inc - need;
-        if (dst + n_out <= W.pool_cap) {
+        const unsigned long long loc = wbase + inc - need;   // inside the shard's part of the pool
+        const unsigned long long dst = (unsigned long long)shard * W.mpool_shard_cap + loc;
+        if (loc + n_out <= W.mpool_shard_cap) {
             uint32_t p = 0, k = 0;
             while (p != kNone) {
                 const uint32_t w = sy[p];
@@ -1053,7 +1058,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
     const int tid = threadIdx.x;
     for (int i = tid; i < 256; i += kMergeThreads) byte_tok[i] = T.byte_tok[i];
     const uint32_t shard = blockIdx.x % kMissShards;
-    uint64_t n_ent = W.status->miss_count[shard];
+    uint64_t n_ent = W.status->shard[shard].miss_count;
     if (n_ent > W.miss_shard_cap) n_ent = W.miss_shard_cap;
     const uint64_t stride = (uint64_t)(gridDim.x / kMissShards) * kMergeThreads;
     __syncthreads();
@@ -1065,6 +1070,10 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
         mi.len = 0; mi.tile = 0; mi.start = 0; mi.w[0] = mi.w[1] = mi.w[2] = mi.w[3] = 0;
         if (have) mi = W.miss_in[ei];
         const uint32_t len = mi.len;
+#if L3_MERGE_STOP == 1
+        if (have) W.miss_res[ei] = 1;
+        continue;
+#endif
         // ---- up to 16 bytes: every lane in its own 16-element slot
         {
             const bool act = have && len >= 1 && len <= 16;
@@ -1082,9 +1091,15 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
                     sy[j] = (uint32_t)byte_tok[bb[j]] | (nxt << 17) | (prv << 24);
                     pq[j] = (j < 15 && pp[j < 15 ? j : 0] != kNoPrio && (uint32_t)j < len) ? (pp[j < 15 ? j : 0] << 7) | (uint32_t)j : 0xFFFFFFFFu;
                 }
+#if L3_MERGE_STOP != 2
                 lane_merge<16>(T, sy, pq);
+#endif
             }
-            lane_finish(W, sy, act, ei, mi.tile);
+#if L3_MERGE_STOP == 2 || L3_MERGE_STOP == 3
+            if (act) W.miss_res[ei] = 1 | ((uint64_t)(sy[0] & 0x1FFFFu) << 8);
+#else
+            lane_finish(W, sy, act, ei, mi.tile, shard);
+#endif
         }
         // ---- 17..64 bytes: groups of 64 lanes, 64-element slots of the same arena
         const bool is_long = have && len > 16;
@@ -1114,7 +1129,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
                     lane_merge<64>(T, sy, pq);
                 }
                 // all four waves take part (lanes of a group are spread over them)
-                lane_finish(W, sy, act, ei, mi.tile);
+                lane_finish(W, sy, act, ei, mi.tile, shard);
                 __syncthreads();
             }
         }
@@ -1403,12 +1418,12 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
                 if (!fits) atomicOr(&W.status->flags, kOvfPool);
                 lvars[4] = fits ? (long long)off : -1ll;
                 W.slow[ei].count = n_out;
-                W.slow[ei].pool_off = off;
+                W.slow[ei].pool_off = (unsigned long long)kMissShards * W.mpool_shard_cap + off;
                 if (n_out > 1) atomicAdd(&W.tile_extra[W.slow[ei].tile], n_out - 1);
             }
             __syncthreads();
             if (lvars[4] >= 0) {
-                int32_t* dst = W.pool + lvars[4];
+                int32_t* dst = W.pool + (unsigned long long)kMissShards * W.mpool_shard_cap + lvars[4];
                 for (uint32_t i = tid; i < n_out; i += kSlowThreads) dst[i] = sa[i] & kIdMask;
             }
         }
