@@ -83,6 +83,9 @@ int l3_token_bytes(const l3_ctx* ctx, int32_t id, uint8_t* out, size_t cap);
  * [6] first kernel start -> last kernel end.  Returns the number of values written. */
 int l3_set_profiling(l3_ctx* ctx, int enabled);
 int l3_last_timings(l3_ctx* ctx, float* ms, int cap);
+/* the same seven values summed over the *calls profiled encode calls since l3_set_profiling() was last called (every
+ * call of it resets the sums), so a benchmark loop need not ask after every step */
+int l3_timing_totals(l3_ctx* ctx, double* ms, int cap, uint64_t* calls);
 /* counters of the last encode call: [0] tiles, [1] deferred (slow) pre-tokens, [2] tokens of all
  * deferred pre-tokens, [3] scratch bytes, [4] retries after a workspace grew, [5] short deferred pre-tokens */
 int l3_last_counters(l3_ctx* ctx, uint64_t* out, int cap);

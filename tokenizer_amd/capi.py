@@ -39,6 +39,7 @@ SYMBOLS = [
     ("l3_token_bytes", C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     ("l3_set_profiling", C.c_int, [_P, C.c_int]),
     ("l3_last_timings", C.c_int, [_P, _P, C.c_int]),
+    ("l3_timing_totals", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64)]),
     ("l3_last_counters", C.c_int, [_P, _P, C.c_int]),
 ]
 
@@ -208,6 +209,13 @@ class Context:
         a = np.zeros(7, dtype=np.float32)
         self.lib.l3_last_timings(self.h, a.ctypes.data, 7)
         return dict(zip(["docs", "tile", "merge", "slow", "scan", "emit", "total"], a.tolist()))
+
+    def timing_totals(self):
+        """(sums of the seven timings over the profiled calls since set_profiling, number of those calls)"""
+        a = np.zeros(7, dtype=np.float64)
+        n = C.c_uint64(0)
+        self.lib.l3_timing_totals(self.h, a.ctypes.data, 7, C.byref(n))
+        return dict(zip(["docs", "tile", "merge", "slow", "scan", "emit", "total"], a.tolist())), int(n.value)
 
     def last_counters(self):
         a = np.zeros(6, dtype=np.uint64)

@@ -54,6 +54,8 @@ struct l3_ctx {
     hipEvent_t ev[kEvCount] = {};
     bool have_events = false, profiling = false;
     float last_ms[kEvCount] = {};
+    double sum_ms[kEvCount] = {};     // over the profiled calls since profiling was switched on
+    uint64_t sum_calls = 0;
     uint64_t counters[6] = {0, 0, 0, 0, 0, 0};
     std::unordered_map<std::string, int> special_by_name;
     std::mutex mu;
@@ -214,6 +216,8 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
             }
             HIPCHK(c, hipEventElapsedTime(&total, c->ev[kEvStart], c->ev[kEvEmit]));
             c->last_ms[kEvCount - 1] = total;
+            for (int i = 0; i < kEvCount; i++) c->sum_ms[i] += c->last_ms[i];
+            c->sum_calls++;
         }
         c->counters[0] = n_tiles;
         c->counters[1] = st.slow_count;
@@ -474,6 +478,8 @@ int l3_set_profiling(l3_ctx* c, int enabled) {
     if (!c) return L3_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     c->profiling = enabled != 0;
+    for (int i = 0; i < kEvCount; i++) c->sum_ms[i] = 0;
+    c->sum_calls = 0;
     return L3_OK;
 }
 
@@ -482,6 +488,15 @@ int l3_last_timings(l3_ctx* c, float* ms, int cap) {
     std::lock_guard<std::mutex> lk(c->mu);
     int n = cap < kEvCount ? cap : kEvCount;
     for (int i = 0; i < n; i++) ms[i] = c->last_ms[i];
+    return n;
+}
+
+int l3_timing_totals(l3_ctx* c, double* ms, int cap, uint64_t* calls) {
+    if (!c || !ms || !calls) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int n = cap < kEvCount ? cap : kEvCount;
+    for (int i = 0; i < n; i++) ms[i] = c->sum_ms[i];
+    *calls = c->sum_calls;
     return n;
 }
 
