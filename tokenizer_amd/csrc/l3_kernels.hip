@@ -270,13 +270,16 @@ constexpr int kRareCap = 512;
 struct TileLds {
     uint8_t b[kRegion + 16];
     u64 bm[B_COUNT][kWords + 2];
-    uint16_t list[kTile];      // compacted own pre-token starts (region-local offsets)
+    union {
+        uint16_t list[kTile];  // compacted own pre-token starts (region-local offsets)
+        uint4 ctab[256];       // before that: class bits of every byte value, see the classification step
+    };
     uint16_t wpre[kWords + 1]; // own pre-token starts before each mask word
     uint16_t rare[kRareCap];   // list index k of the pre-tokens left to the second lookup pass
 };
 constexpr int kListPer = 16;
 static_assert(kListPer * kTileThreads >= kTile && 64 % kListPer == 0 && kBack % kListPer == 0, "list compaction geometry");
-enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NMISS, TV_NSLOW, TV_MISS0, TV_SLOW0, TV_NRARE, TV_COUNT = 8 };
+enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NMISS, TV_NSLOW, TV_MISS0, TV_SLOW0, TV_NRARE, TV_ANYINV, TV_LASTE, TV_COUNT = 16 };
 
 struct TileSrc {  // byte source over the tile's LDS image, LOCAL coordinates [0, n)
     const TileLds* R;
@@ -534,7 +537,20 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     for (int i = tid; i < kWords + 2; i += kTileThreads) {
         R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0; R.bm[B_CE2][i] = 0; R.bm[B_CE3][i] = 0;
     }
-    if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; vars[TV_NRARE] = 0; }
+    if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; vars[TV_NRARE] = 0; vars[TV_ANYINV] = 0; }
+    {   // class table entry of byte value `tid` (state_machine.go:310-320 for ASCII: letters, Nd digits, unicode.IsSpace)
+        const uint32_t v = (uint32_t)tid;
+        const uint32_t f = v | 0x20u;
+        const uint32_t asc = v < 0x80u ? 1u : 0u;
+        const uint32_t cl = (f >= 'a' && f <= 'z') ? asc : 0u;
+        const uint32_t cn = (v >= '0' && v <= '9') ? 1u : 0u;
+        const uint32_t cnl = (v == '\n' || v == '\r') ? 1u : 0u;
+        const uint32_t csp = v == ' ' ? 1u : 0u;
+        const uint32_t cws = (v >= 9u && v <= 13u && !cnl) ? 1u : 0u;
+        const uint32_t cap = v == '\'' ? 1u : 0u;
+        const uint32_t clt = v == '<' ? 1u : 0u;
+        R.ctab[tid] = make_uint4(asc | (cl << 16), cn | (cnl << 16), csp | (cws << 16), cap | (clt << 16));
+    }
     const int c0 = tid * 16;            // region bytes [c0, c0 + 16) are classified by this thread
     const bool cls_thread = tid < kRegion / 16;
     uint32_t xw[4] = {0, 0, 0, 0};
@@ -559,38 +575,25 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         if (pos >= g_hi) break;
         atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
     }
-    // -- ASCII bytes: classes of four bytes at a time (bit 7 of every byte of a word = the property)
+    // -- ASCII bytes by table: ctab[v] holds the eight class bits of byte value v spread over four words, two
+    //    classes per word at bits 0 and 16 (x: rune start | letter, y: digit | newline, z: blank | other white
+    //    space, w: apostrophe | '<'); OR-ing the entry of byte p shifted left by p gathers, for each class, the
+    //    16-bit mask of this thread's bytes.  One 16-byte LDS read and four shift-ORs per byte (the arithmetic
+    //    version of this step took 29 ALU operations per byte).  Bytes >= 0x80 have an all-zero entry.
     uint32_t m_rs = 0, m_l = 0, m_n = 0, m_nl = 0, m_sp = 0, m_ws = 0, m_apos = 0, m_lt = 0;
     if (cls_thread) {
         const uint32_t valid = c0 + 16 <= n ? 0xFFFFu : (c0 < n ? (1u << (n - c0)) - 1u : 0u);
-        // gathers bit 7 of the four bytes of m into bits 0..3
-        auto mm = [](uint32_t m) {
-            uint32_t y = m >> 7;
-            y |= y >> 7;
-            y |= y >> 14;
-            return y & 0xFu;
-        };
+        uint32_t ax = 0, ay = 0, az = 0, aw = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t w = xw[k];
-            const uint32_t asc = ~w & 0x80808080u;
-            const uint32_t t7 = w & 0x7F7F7F7Fu;
-            const uint32_t f = t7 | 0x20202020u;
-#define L3_GE(x, c) (((x) + (0x80u - (uint32_t)(c)) * 0x01010101u) & 0x80808080u)
-#define L3_EQ(x, c) (~(((x) ^ ((uint32_t)(c) * 0x01010101u)) + 0x7F7F7F7Fu) & 0x80808080u)
-            const uint32_t cl = L3_GE(f, 'a') & ~L3_GE(f, 'z' + 1) & asc;
-            const uint32_t cn = L3_GE(t7, '0') & ~L3_GE(t7, '9' + 1) & asc;
-            const uint32_t csp = L3_EQ(t7, ' ') & asc;
-            const uint32_t cnl = (L3_EQ(t7, '\n') | L3_EQ(t7, '\r')) & asc;
-            const uint32_t cws = L3_GE(t7, 9) & ~L3_GE(t7, 14) & asc & ~cnl;
-            const uint32_t cap = L3_EQ(t7, '\'') & asc;
-            const uint32_t clt = L3_EQ(t7, '<') & asc;
-#undef L3_GE
-#undef L3_EQ
-            m_rs |= mm(asc) << (4 * k); m_l |= mm(cl) << (4 * k); m_n |= mm(cn) << (4 * k); m_nl |= mm(cnl) << (4 * k);
-            m_sp |= mm(csp) << (4 * k); m_ws |= mm(cws) << (4 * k); m_apos |= mm(cap) << (4 * k); m_lt |= mm(clt) << (4 * k);
+        for (int p = 0; p < 16; p++) {
+            const uint32_t v = (xw[p >> 2] >> ((p & 3) * 8)) & 0xFFu;
+            const uint4 e = R.ctab[v];
+            ax |= e.x << p; ay |= e.y << p; az |= e.z << p; aw |= e.w << p;
         }
-        m_rs &= valid; m_l &= valid; m_n &= valid; m_nl &= valid; m_sp &= valid; m_ws &= valid; m_apos &= valid; m_lt &= valid;
+        m_rs = ax & valid; m_l = (ax >> 16) & valid;
+        m_n = ay & valid; m_nl = (ay >> 16) & valid;
+        m_sp = az & valid; m_ws = (az >> 16) & valid;
+        m_apos = aw & valid; m_lt = (aw >> 16) & valid;
     }
     __syncthreads();
 
@@ -614,6 +617,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                 if (wd & I_INVALID) m_inv |= bit;
             }
         }
+        if (m_inv) vars[TV_ANYINV] = 1;   // (every writer stores the same value)
         uint32_t ap = m_apos;
         while (ap) {
             const int q = c0 + __builtin_ctz(ap);
@@ -751,27 +755,97 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     int32_t* res = reinterpret_cast<int32_t*>(&R.bm[B_LIVE][0]);
     int32_t* out0 = W.stream + tile * (uint64_t)kTileCap;
     // -- per pre-token: special id / whole-string vocabulary probe (bpe.go:27-33) / defer.  One stream item each.
-    //    Two passes over the same code: the first does the common case (up to 12 valid bytes, no special token) and
-    //    only lists the others; the second does the listed ones, densely packed.  Otherwise one rare pre-token
-    //    among the 64 of a wave iteration makes the whole wave walk the long path (six iterations in ten on C2).
+    //    The common case (up to 12 valid bytes, no special token) is done kLookU pre-tokens per thread at a time, in
+    //    stages, so that the table loads of a whole batch are in flight together: a tile is latency-bound, not
+    //    issue-bound.  Everything else is only listed here and done by the generic loop below, densely packed.
+    if (tid == 0) {   // end of the last own pre-token (the others end where the next one starts)
+        int e = n_pre ? find_next_bit64(ST, (int)R.list[n_pre - 1] + 1, eval_hi) : -1;
+        if (e < 0 && hard) e = n;
+        vars[TV_LASTE] = e;
+    }
+    __syncthreads();
+    {
+        const bool any_inv = vars[TV_ANYINV] != 0;
+        const int last_e = vars[TV_LASTE];
+        constexpr int kLookU = 4;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        const uint32_t n_iter = pass == 0 ? n_pre : ((uint32_t)vars[TV_NRARE] < (uint32_t)kRareCap ? (uint32_t)vars[TV_NRARE] : (uint32_t)kRareCap);
+        for (uint32_t base = 0; base < n_pre; base += kTileThreads * kLookU) {
+            uint32_t w0[kLookU], w1[kLookU], w2[kLookU], ln[kLookU], hb2[kLookU];
+            VocabSlot sl[kLookU];
+            bool probe[kLookU], again[kLookU];
+#pragma unroll
+            for (int u = 0; u < kLookU; u++) {
+                const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
+                probe[u] = false;
+                if (k < n_pre) {
+                    const int s = R.list[k];
+                    const int e = k + 1 < n_pre ? (int)R.list[k + 1] : last_e;
+                    const int len = e - s;
+                    const bool special = (R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull;
+                    const bool inval = any_inv && e >= 0 && any_bit_in(R.bm[B_INV], s, e);
+                    if (special || e < 0 || inval || len > kVocabInline) {
+                        const uint32_t idx = (uint32_t)atomicAdd(&vars[TV_NRARE], 1);
+                        if (idx < (uint32_t)kRareCap) R.rare[idx] = (uint16_t)k;
+                    } else {
+                        // little-endian words of the pre-token straight from the LDS image (unaligned start)
+                        const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
+                        const uint32_t sh = (uint32_t)(s & 3) * 8u;
+                        const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
+                        const uint32_t nw = ((uint32_t)len + 3u) >> 2;
+                        const uint32_t tail = (len & 3) ? (1u << ((len & 3) * 8)) - 1u : 0xFFFFFFFFu;
+                        uint32_t a0 = __funnelshift_r(x0, x1, sh), a1 = __funnelshift_r(x1, x2, sh), a2 = __funnelshift_r(x2, x3, sh);
+                        if (nw == 1) { a0 &= tail; a1 = 0; a2 = 0; }
+                        else if (nw == 2) { a1 &= tail; a2 = 0; }
+                        else a2 &= tail;
+                        w0[u] = a0; w1[u] = a1; w2[u] = a2; ln[u] = (uint32_t)len;
+                        uint32_t hb1;
+                        vocab_hash_short2(a0, a1, a2, (uint32_t)len, T.vocab_log2, &hb1, &hb2[u]);
+                        sl[u] = T.vocab_slots[hb1];
+                        probe[u] = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kLookU; u++) {   // first choice missed: second bucket (tokens that lost their first choice, non-tokens)
+                again[u] = false;
+                if (probe[u]) {
+                    const bool hit = (sl[u].w[3] & ~0x1FFFFu) == (ln[u] << 17) && sl[u].w[0] == w0[u] && sl[u].w[1] == w1[u] && sl[u].w[2] == w2[u];
+                    if (!hit) { sl[u] = T.vocab_slots[hb2[u]]; again[u] = true; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kLookU; u++) {
+                if (probe[u]) {
+                    const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
+                    const bool hit = (sl[u].w[3] & ~0x1FFFFu) == (ln[u] << 17) && sl[u].w[0] == w0[u] && sl[u].w[1] == w1[u] && sl[u].w[2] == w2[u];
+                    int32_t item;
+                    if (hit) item = (int32_t)(sl[u].w[3] & 0x1FFFFu);
+                    else item = -2 - (int32_t)atomicAdd(&vars[TV_NMISS], 1);  // local ordinal (<= 12 valid bytes: a lane merges it)
+                    // deferred: the local ordinal for now, replaced below by the global entry index.  Staged in LDS (the
+                    // bitmap rows that are dead by now); text of one- and two-byte pre-tokens can exceed it and goes
+                    // straight to HBM
+                    if (k < (uint32_t)kResCap) res[k] = item; else out0[k] = item;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // generic loop: the listed pre-tokens, or all of them again when the list overflowed (then the counters restart)
+    const bool rare_all = (uint32_t)vars[TV_NRARE] > (uint32_t)kRareCap;
+    __syncthreads();
+    if (rare_all && tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; }
+    if (rare_all) __syncthreads();
+    {
+        const uint32_t n_iter = rare_all ? n_pre : (uint32_t)vars[TV_NRARE];
 #pragma unroll 1
         for (uint32_t it = tid; it < n_iter; it += kTileThreads) {
-            const uint32_t k = pass == 0 ? it : (uint32_t)R.rare[it];
+            const uint32_t k = rare_all ? it : (uint32_t)R.rare[it];
             const int s = R.list[k];
             const bool special = (R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull;
             int e = find_next_bit64(ST, s + 1, eval_hi);
             if (e < 0 && hard) e = n;
             const int len = e - s;
             const bool inval = e >= 0 && any_bit_in(R.bm[B_INV], s, e);
-            const bool rare = special || e < 0 || inval || len > kVocabInline;
-            if (pass == 0 && rare) {
-                const uint32_t idx = (uint32_t)atomicAdd(&vars[TV_NRARE], 1);
-                if (idx < (uint32_t)kRareCap) { R.rare[idx] = (uint16_t)k; continue; }
-                // list full: done here and now
-            }
             int32_t item;
             if (special) {
                 int canon = 0;
@@ -779,39 +853,24 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                 item = T.special_id[canon];
             } else {
                 int32_t id = -1;
-                if (e >= 0 && !inval && len <= kMaxTokenBytes && !L3_DBG(A.flags, 0x200u)) {
-                    // little-endian words of the pre-token straight from the LDS image (unaligned start)
+                if (e >= 0 && !inval && len <= kMaxTokenBytes) {
                     const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
                     const uint32_t sh = (uint32_t)(s & 3) * 8u;
                     const uint32_t nw = ((uint32_t)len + 3u) >> 2;
                     const uint32_t tail = (len & 3) ? (1u << ((len & 3) * 8)) - 1u : 0xFFFFFFFFu;
-                    if (!rare) {
-                        const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
-                        uint32_t w0 = __funnelshift_r(x0, x1, sh), w1 = __funnelshift_r(x1, x2, sh), w2 = __funnelshift_r(x2, x3, sh);
-                        if (nw == 1) { w0 &= tail; w1 = 0; w2 = 0; }
-                        else if (nw == 2) { w1 &= tail; w2 = 0; }
-                        else w2 &= tail;
-                        if (L3_DBG(A.flags, 0x400u)) id = (int32_t)((w0 ^ w1 ^ w2) & 0xFFFFu);
-                        else id = vocab_lookup_short(T, w0, w1, w2, (uint32_t)len);
-                    } else {
-                        id = vocab_lookup_words(T, [&](uint32_t i) {
-                            uint32_t x = __funnelshift_r(wp[i], wp[i + 1], sh);
-                            return i + 1 == nw ? x & tail : x;
-                        }, (uint32_t)len);
-                    }
-                } else if (L3_DBG(A.flags, 0x200u)) {
-                    id = 1;
+                    id = vocab_lookup_words(T, [&](uint32_t i) {
+                        uint32_t x = __funnelshift_r(wp[i], wp[i + 1], sh);
+                        return i + 1 == nw ? x & tail : x;
+                    }, (uint32_t)len);
                 }
                 if (id >= 0) item = id;
                 else if (e >= 0 && !inval && len <= kLaneMax) item = -2 - (int32_t)atomicAdd(&vars[TV_NMISS], 1);  // local ordinal
                 else item = -2 - (int32_t)(kSlowBase + (uint32_t)atomicAdd(&vars[TV_NSLOW], 1));
             }
-            // deferred: the local ordinal for now, replaced below by the global entry index.  Staged in LDS (the bitmap
-            // rows that are dead by now); text of one- and two-byte pre-tokens can exceed it and goes straight to HBM
             if (k < (uint32_t)kResCap) res[k] = item; else out0[k] = item;
         }
-        __syncthreads();
     }
+    __syncthreads();
     L3_STOP_AFTER(4)
     const uint32_t shard = (uint32_t)(tile % kMissShards);
     if (tid == 0) {
