@@ -513,7 +513,7 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
 #define L3_MERGE_STOP 0
 #endif
 #ifndef L3_TILE_OCC
-#define L3_TILE_OCC 6
+#define L3_TILE_OCC 7
 #endif
 __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables T, Workspace W, EncodeArgs A) {
     __shared__ __align__(16) TileLds R;
@@ -728,6 +728,11 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     // -- compacted list of own pre-token starts (kListPer byte positions per thread; own_lo is 0 or kBack, so a
     //    thread's positions never straddle a 64-bit mask word)
     {
+        if (tid == kTileThreads - 1) {   // end of the last own pre-token (the others end where the next one starts):
+            int e = find_next_bit64(ST, own_hi, eval_hi);   // the first start past the own range
+            if (e < 0 && hard) e = n;
+            vars[TV_LASTE] = e;
+        }
         const int pos = own_lo + tid * kListPer;
         if (pos < own_hi) {
             const int wd = pos >> 6, sh = pos & 63;
@@ -758,16 +763,13 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     //    The common case (up to 12 valid bytes, no special token) is done kLookU pre-tokens per thread at a time, in
     //    stages, so that the table loads of a whole batch are in flight together: a tile is latency-bound, not
     //    issue-bound.  Everything else is only listed here and done by the generic loop below, densely packed.
-    if (tid == 0) {   // end of the last own pre-token (the others end where the next one starts)
-        int e = n_pre ? find_next_bit64(ST, (int)R.list[n_pre - 1] + 1, eval_hi) : -1;
-        if (e < 0 && hard) e = n;
-        vars[TV_LASTE] = e;
-    }
-    __syncthreads();
     {
         const bool any_inv = vars[TV_ANYINV] != 0;
         const int last_e = vars[TV_LASTE];
-        constexpr int kLookU = 4;
+#ifndef L3_LOOK_U
+#define L3_LOOK_U 4
+#endif
+        constexpr int kLookU = L3_LOOK_U;
 #pragma unroll 1
         for (uint32_t base = 0; base < n_pre; base += kTileThreads * kLookU) {
             uint32_t w0[kLookU], w1[kLookU], w2[kLookU], ln[kLookU], hb2[kLookU];
@@ -831,10 +833,12 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     }
     __syncthreads();
     // generic loop: the listed pre-tokens, or all of them again when the list overflowed (then the counters restart)
-    const bool rare_all = (uint32_t)vars[TV_NRARE] > (uint32_t)kRareCap;
-    __syncthreads();
-    if (rare_all && tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; }
-    if (rare_all) __syncthreads();
+    const bool rare_all = (uint32_t)vars[TV_NRARE] > (uint32_t)kRareCap;   // uniform over the workgroup
+    if (rare_all) {
+        __syncthreads();
+        if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; }
+        __syncthreads();
+    }
     {
         const uint32_t n_iter = rare_all ? n_pre : (uint32_t)vars[TV_NRARE];
 #pragma unroll 1
@@ -873,15 +877,37 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     __syncthreads();
     L3_STOP_AFTER(4)
     const uint32_t shard = (uint32_t)(tile % kMissShards);
+    // space in the shard's entry list: one returning atomic per tile, issued here and first needed after the
+    // document loop below, so that its round trip overlaps with that loop
+    uint32_t m0_r = 0, s0_r = 0, nm_r = 0, ns_r = 0;
     if (tid == 0) {
-        const uint32_t nm = (uint32_t)vars[TV_NMISS], ns = (uint32_t)vars[TV_NSLOW];
-        uint32_t m0 = nm ? atomicAdd(&W.status->shard[shard].miss_count, nm) : 0u;
-        uint32_t s0 = ns ? atomicAdd(&W.status->slow_count, ns) : 0u;
-        if (nm && (uint64_t)m0 + nm > W.miss_shard_cap) atomicOr(&W.status->flags, kOvfMiss);
-        if (ns && (uint64_t)s0 + ns > W.slow_cap) atomicOr(&W.status->flags, kOvfSlow);
-        vars[TV_MISS0] = (int)m0;
-        vars[TV_SLOW0] = (int)s0;
+        nm_r = (uint32_t)vars[TV_NMISS]; ns_r = (uint32_t)vars[TV_NSLOW];
+        m0_r = nm_r ? atomicAdd(&W.status->shard[shard].miss_count, nm_r) : 0u;
+        s0_r = ns_r ? atomicAdd(&W.status->slow_count, ns_r) : 0u;
         W.tile_items[tile] = n_pre;
+    }
+    // -- stream index of the first item of every document that starts in this tile
+    {
+        const bool last_tile = tile + 1 == gridDim.x;
+        const uint64_t d_end = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
+        for (uint64_t d = (uint64_t)d0 + tid; d < d_end; d += kTileThreads) {
+            const int pos = (int)(A.doc_off[d] - g_lo);
+            uint32_t item;
+            if (pos >= own_hi) item = n_pre;
+            else {
+                const int wd = pos >> 6, sh = pos & 63;
+                u64 ownw = ST[wd];
+                if (own_lo > wd * 64) ownw &= ~0ull << (own_lo - wd * 64);
+                item = R.wpre[wd] + (uint32_t)__popcll(ownw & ((1ull << sh) - 1ull));
+            }
+            W.doc_item[d] = item;
+        }
+    }
+    if (tid == 0) {
+        if (nm_r && (uint64_t)m0_r + nm_r > W.miss_shard_cap) atomicOr(&W.status->flags, kOvfMiss);
+        if (ns_r && (uint64_t)s0_r + ns_r > W.slow_cap) atomicOr(&W.status->flags, kOvfSlow);
+        vars[TV_MISS0] = (int)m0_r;
+        vars[TV_SLOW0] = (int)s0_r;
     }
     __syncthreads();
     {
@@ -980,23 +1006,6 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                 item = -2 - (int32_t)(uint32_t)ei;
             }
             out[k] = item;
-        }
-    }
-    // -- stream index of the first item of every document that starts in this tile
-    {
-        const bool last_tile = tile + 1 == gridDim.x;
-        const uint64_t d_end = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
-        for (uint64_t d = (uint64_t)d0 + tid; d < d_end; d += kTileThreads) {
-            const int pos = (int)(A.doc_off[d] - g_lo);
-            uint32_t item;
-            if (pos >= own_hi) item = n_pre;
-            else {
-                const int wd = pos >> 6, sh = pos & 63;
-                u64 ownw = ST[wd];
-                if (own_lo > wd * 64) ownw &= ~0ull << (own_lo - wd * 64);
-                item = R.wpre[wd] + (uint32_t)__popcll(ownw & ((1ull << sh) - 1ull));
-            }
-            W.doc_item[d] = item;
         }
     }
 }
@@ -1604,7 +1613,10 @@ constexpr int kEmitItemsPer = 4;
 constexpr int kEmitRound = kTileThreads * kEmitItemsPer;
 constexpr int kDmaskWords = (kTileCap + 64) / 64 + 1;
 static_assert(kDmaskWords <= 64, "one wave scans the document-start words");
-__global__ __launch_bounds__(kTileThreads) void emit_kernel(Workspace W, EncodeArgs A) {
+#ifndef L3_EMIT_OCC
+#define L3_EMIT_OCC 6
+#endif
+__global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspace W, EncodeArgs A) {
     __shared__ int32_t stg[kStage];
     __shared__ unsigned long long dmask[kDmaskWords];
     __shared__ uint32_t wordpre[kDmaskWords];
