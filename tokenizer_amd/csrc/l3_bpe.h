@@ -88,13 +88,23 @@ L3_HD int32_t vocab_lookup_words(const Tables& t, GetW getw, uint32_t len) {
     for (uint32_t i = 0; i < nw; i++) strhash_add(h, getw(i));
     uint32_t b[2];
     strhash_buckets(h, len, t.vocab_log2, &b[0], &b[1]);
-    for (int k = 0; k < 2; k++) {
-        const VocabSlot v = t.vocab_slots[b[k]];
-        if (v.w[3] == kVocabEmpty || (v.w[3] >> 17) != len || v.w[0] != h.h2) continue;
-        const uint32_t* blob = t.vocab_blob + v.w[1];
+    // both candidate slots at once, then the blob words of whichever carries the right length and second hash:
+    // two memory round trips, not four
+    const VocabSlot v0 = t.vocab_slots[b[0]];
+    const VocabSlot v1 = t.vocab_slots[b[1]];
+    const bool c0 = v0.w[3] != kVocabEmpty && (v0.w[3] >> 17) == len && v0.w[0] == h.h2;
+    const bool c1 = v1.w[3] != kVocabEmpty && (v1.w[3] >> 17) == len && v1.w[0] == h.h2;
+    if (c0) {
+        const uint32_t* blob = t.vocab_blob + v0.w[1];
         bool eq = true;
-        for (uint32_t i = 0; i < nw && eq; i++) eq = blob[i] == getw(i);
-        if (eq) return (int32_t)(v.w[3] & 0x1FFFFu);
+        for (uint32_t i = 0; i < nw; i++) eq = eq & (blob[i] == getw(i));
+        if (eq) return (int32_t)(v0.w[3] & 0x1FFFFu);
+    }
+    if (c1) {
+        const uint32_t* blob = t.vocab_blob + v1.w[1];
+        bool eq = true;
+        for (uint32_t i = 0; i < nw; i++) eq = eq & (blob[i] == getw(i));
+        if (eq) return (int32_t)(v1.w[3] & 0x1FFFFu);
     }
     return -1;
 }
