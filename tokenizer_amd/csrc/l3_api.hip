@@ -114,7 +114,7 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     HIPCHK(c, c->w_items.ensure(n_tiles * 4));
     HIPCHK(c, c->w_extra.ensure(n_tiles * 4));
     HIPCHK(c, c->w_base.ensure((n_tiles / 1024 + 2) * 8));
-    HIPCHK(c, c->w_pre.ensure(n_tiles * 8));
+    HIPCHK(c, c->w_pre.ensure(n_tiles * sizeof(TileRec)));
     HIPCHK(c, c->w_flag.ensure(n_tiles * 4));
     HIPCHK(c, c->w_doc0.ensure((n_tiles + 1) * 4));
     HIPCHK(c, c->w_docitem.ensure((n_docs + 1) * 4));
@@ -139,7 +139,7 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     W.tile_items = c->w_items.as<uint32_t>();
     W.tile_extra = c->w_extra.as<uint32_t>();
     W.tile_base = c->w_base.as<uint64_t>();
-    W.tile_pre = c->w_pre.as<uint64_t>();
+    W.tile_rec = c->w_pre.as<TileRec>();
     W.tile_flag = c->w_flag.as<uint32_t>();
     W.tile_doc0 = c->w_doc0.as<uint32_t>();
     W.doc_item = c->w_docitem.as<uint32_t>();

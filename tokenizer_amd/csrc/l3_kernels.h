@@ -78,12 +78,21 @@ struct alignas(16) MissIn {
 };
 constexpr uint32_t kMissInline = 3;   // results of up to this many tokens live in the miss_res word itself
 
+// written by block_totals_kernel once a tile's token count is final
+struct alignas(32) TileRec {
+    uint64_t pre;        // tokens of the tiles of the same block of 1024 that precede the tile
+    uint32_t n_items;    // items in the tile's stream
+    uint32_t n_extra;    // tokens beyond one per item (deferred pre-tokens)
+    uint32_t d_lo, d_hi; // documents that start in the tile: [d_lo, d_hi)
+    uint32_t pad[2];
+};
+
 struct Workspace {
     int32_t* stream;        // [n_tiles * kTileCap] per-tile token stream incl. slow placeholders
     uint32_t* tile_items;   // [n_tiles] items in the tile's stream
     uint32_t* tile_extra;   // [n_tiles] sum of (tokens - 1) over the tile's deferred pre-tokens (atomic adds)
     uint64_t* tile_base;    // [ceil(n_tiles / 1024)] exclusive scan of the token totals of blocks of 1024 tiles
-    uint64_t* tile_pre;     // [n_tiles] tokens of the tiles of the same block that precede the tile
+    TileRec* tile_rec;      // [n_tiles] what the emit kernels need to know about a tile, in one 32-byte load
     uint32_t* tile_flag;    // [n_tiles] 1 = the fast emit kernel left the tile to the generic one
     uint32_t* tile_doc0;    // [n_tiles + 1] first document whose start is >= the tile start
     uint32_t* doc_item;     // [n_docs + 1] stream index (inside its tile) of the document's first item

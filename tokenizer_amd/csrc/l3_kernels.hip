@@ -1502,11 +1502,14 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
 // ---- per-tile output bases: block totals, scan of the block totals -----------------------------------------
 constexpr int kScanThreads = 1024;
 constexpr int kScanBlock = 1024;  // tiles per block total
-__global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, uint64_t n_tiles) {
+__global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, uint64_t n_tiles, uint64_t n_docs) {
     __shared__ unsigned long long wsum[kScanBlock / 64];
     if (W.status->flags & kBadOffsets) return;
     const uint64_t t = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;   // one tile per thread
-    const unsigned long long v = t < n_tiles ? (unsigned long long)W.tile_items[t] + W.tile_extra[t] : 0ull;
+    const uint32_t n_items = t < n_tiles ? W.tile_items[t] : 0u, n_extra = t < n_tiles ? W.tile_extra[t] : 0u;
+    const uint32_t d_lo = t < n_tiles ? W.tile_doc0[t] : 0u;
+    const uint32_t d_hi = t + 1 < n_tiles ? W.tile_doc0[t + 1] : (uint32_t)(n_docs + 1);
+    const unsigned long long v = (unsigned long long)n_items + n_extra;
     unsigned long long inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1522,7 +1525,12 @@ __global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, u
         if (i < (int)(threadIdx.x >> 6)) pre += x;
         tot += x;
     }
-    if (t < n_tiles) W.tile_pre[t] = pre + inc - v;
+    if (t < n_tiles) {
+        TileRec rec;
+        rec.pre = pre + inc - v; rec.n_items = n_items; rec.n_extra = n_extra; rec.d_lo = d_lo; rec.d_hi = d_hi;
+        rec.pad[0] = rec.pad[1] = 0;
+        W.tile_rec[t] = rec;
+    }
     if (threadIdx.x == 0) W.tile_base[blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeArgs A, uint64_t n_blocks) {
@@ -1609,7 +1617,10 @@ __device__ __forceinline__ unsigned long long block_escan64(unsigned long long v
 // coalesced run.  Document starts are a bit per item (tiles with several documents on one item go to the
 // generic kernel, as do tiles with more tokens than the staging buffer holds).
 constexpr int kStage = 3072;
-constexpr int kEmitItemsPer = 4;
+#ifndef L3_EMIT_PER
+#define L3_EMIT_PER 4
+#endif
+constexpr int kEmitItemsPer = L3_EMIT_PER;   // 2 or 4
 constexpr int kEmitRound = kTileThreads * kEmitItemsPer;
 constexpr int kDmaskWords = (kTileCap + 64) / 64 + 1;
 static_assert(kDmaskWords <= 64, "one wave scans the document-start words");
@@ -1625,18 +1636,20 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
     __shared__ int32_t q_item[kEmitQueue];
     __shared__ uint32_t q_n, s_generic;
 
-    const uint32_t fl = W.status->flags;
-    if (fl & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) return;
-    if (W.status->total_tokens > A.out_cap) return;
+    // every parameter load is requested before the first branch: one memory round trip, not three
     const int tid = threadIdx.x;
     const uint64_t tile = blockIdx.x;
-    const bool last_tile = tile + 1 == gridDim.x;
-    const uint32_t n_items = W.tile_items[tile];
-    const uint64_t n_tok = (uint64_t)n_items + W.tile_extra[tile];
-    const uint64_t d_lo = W.tile_doc0[tile];
-    const uint64_t d_hi = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
+    const TileRec rec = W.tile_rec[tile];
+    const unsigned long long blk_base = W.tile_base[tile / kScanBlock];
+    const uint32_t fl = W.status->flags;
+    const unsigned long long total_tokens = W.status->total_tokens;
+    if (fl & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) return;
+    if (total_tokens > A.out_cap) return;
+    const uint32_t n_items = rec.n_items;
+    const uint64_t n_tok = (uint64_t)n_items + rec.n_extra;
+    const uint64_t d_lo = rec.d_lo, d_hi = rec.d_hi;
     const uint32_t bos = A.flags & 1u, eos = (A.flags >> 1) & 1u, be = bos + eos;
-    const unsigned long long base = W.tile_base[tile / kScanBlock] + W.tile_pre[tile];
+    const unsigned long long base = blk_base + rec.pre;
     const int32_t* in = W.stream + tile * (uint64_t)kTileCap;
     const uint64_t n_tdocs = d_hi - d_lo;
     if (n_tok + (n_tdocs + 1) * be > (uint64_t)kStage || n_tdocs > (uint64_t)n_items + 1) {
@@ -1673,8 +1686,13 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
         const uint32_t i0 = r * kEmitRound + (uint32_t)tid * kEmitItemsPer;
         int32_t item[kEmitItemsPer];
         if (i0 + kEmitItemsPer <= n_items) {
-            const int4 v = *reinterpret_cast<const int4*>(in + i0);
-            item[0] = v.x; item[1] = v.y; item[2] = v.z; item[3] = v.w;
+            if constexpr (kEmitItemsPer == 4) {
+                const int4 v = *reinterpret_cast<const int4*>(in + i0);
+                item[0] = v.x; item[1] = v.y; item[2] = v.z; item[kEmitItemsPer - 1] = v.w;
+            } else {
+                const int2 v = *reinterpret_cast<const int2*>(in + i0);
+                item[0] = v.x; item[kEmitItemsPer - 1] = v.y;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < kEmitItemsPer; j++) item[j] = i0 + j < n_items ? in[i0 + j] : kDead;
@@ -1689,9 +1707,11 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
             inl[j] = false;
             if (item[j] < kDead) deferred_result(W, item[j], &poff[j], &cnt[j], &inl[j]);
         }
-        const uint32_t dbits = i0 <= n_items ? (uint32_t)(dmask[i0 >> 6] >> (i0 & 63)) & 0xFu : 0u;  // i0 % 4 == 0: one word
+        const uint32_t dbits = i0 <= n_items ? (uint32_t)(dmask[i0 >> 6] >> (i0 & 63)) & ((1u << kEmitItemsPer) - 1u) : 0u;  // i0 % kEmitItemsPer == 0: one word
         const uint32_t dprev = i0 <= n_items ? wordpre[i0 >> 6] + (uint32_t)__popcll(dmask[i0 >> 6] & ((1ull << (i0 & 63)) - 1ull)) : 0u;
-        const uint32_t csum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        uint32_t csum = 0;
+#pragma unroll
+        for (int j = 0; j < kEmitItemsPer; j++) csum += cnt[j];
         unsigned long long tot;
         const unsigned long long ex = carry + block_escan64((unsigned long long)csum, tmp64, &tot);
         carry += tot;
@@ -1763,7 +1783,7 @@ __device__ void emit_tile_generic(const Workspace& W, const EncodeArgs& A, uint6
     for (int i = tid; i <= (int)n_items; i += kTileThreads) docinc[i] = 0;
     if (tid == 0) q_n = 0;
     // tokens before this tile: scanned block base + the tiles of the block that precede it
-    const unsigned long long base = W.tile_base[tile / kScanBlock] + W.tile_pre[tile];
+    const unsigned long long base = W.tile_base[tile / kScanBlock] + W.tile_rec[tile].pre;
     for (uint64_t d = d_lo + tid; d < d_hi; d += kTileThreads) atomicAdd(&docinc[W.doc_item[d]], 1u);
     __syncthreads();
 
@@ -1954,7 +1974,7 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         L3_LAUNCH_CHECK();
         L3_EV(kEvSlow);
         const uint64_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
-        hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks), dim3(kScanBlock), 0, stream, W, n_tiles);
+        hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks), dim3(kScanBlock), 0, stream, W, n_tiles, A.n_docs);
         L3_LAUNCH_CHECK();
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, W, A, n_blocks);
         L3_LAUNCH_CHECK();
