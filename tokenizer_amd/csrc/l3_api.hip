@@ -307,12 +307,9 @@ void l3_destroy(l3_ctx* c) {
 
 const char* l3_last_error(const l3_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
-// flags are L3_BOS | L3_EOS | L3_NO_SPECIAL (the measurement builds of tools/build_variant.sh accept more)
+// flags are L3_BOS | L3_EOS | L3_NO_SPECIAL
 static bool bad_flags(l3_ctx* c, uint32_t flags) {
-#ifndef L3_DEBUG_FLAGS
     if (flags & ~(L3_BOS | L3_EOS | L3_NO_SPECIAL)) { c->err = "unknown bits in flags"; return true; }
-#endif
-    (void)c; (void)flags;
     return false;
 }
 

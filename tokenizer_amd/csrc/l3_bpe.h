@@ -25,16 +25,9 @@ L3_HD uint32_t pair_prio(const Tables& t, uint32_t a, uint32_t b) {
     const uint64_t key = pair_key(a, b);
     uint32_t b1, b2;
     pair_hash2(a, b, t.pair_log2, &b1, &b2);
-#if defined(L3_EXP_NOPROBE)
-    return kNoPrio;
-#elif defined(L3_EXP_ONEBUCKET)
-    const PairBucket u = t.pair_buckets[b1];
-    return pair_pick(key, u, u);
-#else
     const PairBucket u = t.pair_buckets[b1];
     const PairBucket v = t.pair_buckets[b2];
     return pair_pick(key, u, v);
-#endif
 }
 // two independent probes: four loads in flight together
 L3_HD void pair_prio2(const Tables& t, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t* r0, uint32_t* r1) {
@@ -42,21 +35,12 @@ L3_HD void pair_prio2(const Tables& t, uint32_t a0, uint32_t b0, uint32_t a1, ui
     uint32_t p0, q0, p1, q1;
     pair_hash2(a0, b0, t.pair_log2, &p0, &q0);
     pair_hash2(a1, b1, t.pair_log2, &p1, &q1);
-#if defined(L3_EXP_NOPROBE)
-    *r0 = kNoPrio; *r1 = kNoPrio;
-#elif defined(L3_EXP_ONEBUCKET)
-    const PairBucket u0 = t.pair_buckets[p0];
-    const PairBucket u1 = t.pair_buckets[p1];
-    *r0 = pair_pick(k0, u0, u0);
-    *r1 = pair_pick(k1, u1, u1);
-#else
     const PairBucket u0 = t.pair_buckets[p0];
     const PairBucket v0 = t.pair_buckets[q0];
     const PairBucket u1 = t.pair_buckets[p1];
     const PairBucket v1 = t.pair_buckets[q1];
     *r0 = pair_pick(k0, u0, v0);
     *r1 = pair_pick(k1, u1, v1);
-#endif
 }
 
 // Whole-string probe for a string of <= 12 bytes given as three zero-padded words.  First-choice bucket first; the
@@ -67,10 +51,6 @@ L3_HD int32_t vocab_lookup_short(const Tables& t, uint32_t w0, uint32_t w1, uint
     vocab_hash_short2(w0, w1, w2, len, t.vocab_log2, &b1, &b2);
     const uint32_t tag_lo = len << 17;
     const VocabSlot s0 = t.vocab_slots[b1];
-#ifdef L3_VOCAB_PARALLEL
-    const VocabSlot sp = t.vocab_slots[b2];
-    if ((sp.w[3] & ~0x1FFFFu) == tag_lo && sp.w[0] == w0 && sp.w[1] == w1 && sp.w[2] == w2) return (int32_t)(sp.w[3] & 0x1FFFFu);
-#endif
     if ((s0.w[3] & ~0x1FFFFu) == tag_lo && s0.w[0] == w0 && s0.w[1] == w1 && s0.w[2] == w2) return (int32_t)(s0.w[3] & 0x1FFFFu);
     const VocabSlot s1 = t.vocab_slots[b2];
     if ((s1.w[3] & ~0x1FFFFu) == tag_lo && s1.w[0] == w0 && s1.w[1] == w1 && s1.w[2] == w2) return (int32_t)(s1.w[3] & 0x1FFFFu);

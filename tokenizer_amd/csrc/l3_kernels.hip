@@ -31,7 +31,6 @@ constexpr int kPer = kSRegion / kTileThreads;  // consecutive region positions o
 static_assert(kPer * kTileThreads == kSRegion, "region must split evenly over the workgroup");
 static_assert(kPer <= 32, "per-thread masks are 32 bit");
 constexpr int kBitWords = kSRegion / 32 + 2;
-constexpr uint32_t I_DOFF_SHIFT = 12;  // bits 12..13 of an info word: offset inside a digit run, mod 3
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -486,32 +485,6 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
     return flags;
 }
 
-// measurement knobs of tools/phase_timing.py (skip the merge loop / the vocabulary probe): compiled in only for the
-// A/B variants built with -DL3_DEBUG_FLAGS, never in the shipped library
-#ifdef L3_DEBUG_FLAGS
-#define L3_DBG(flags, bit) ((flags) & (bit))
-#else
-#define L3_DBG(flags, bit) false
-#endif
-
-// measurement only (tools/build_variant.sh NAME "-DL3_TILE_STOP=n"): leave the tile kernel after phase n (1 load +
-// classify, 2 start bits, 3 list, 4 vocabulary probes) with an empty but well-formed tile, so that the later kernels
-// stay in bounds
-#ifdef L3_TILE_STOP
-#define L3_STOP_AFTER(nphase)                                                                                  \
-    if (L3_TILE_STOP == (nphase)) {                                                                            \
-        if (tid == 0) W.tile_items[tile] = 0;                                                                  \
-        const uint64_t de_ = tile + 1 == gridDim.x ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];           \
-        for (uint64_t d = (uint64_t)d0 + tid; d < de_; d += kTileThreads) W.doc_item[d] = 0;                   \
-        return;                                                                                                \
-    }
-#else
-#define L3_STOP_AFTER(nphase)
-#endif
-
-#ifndef L3_MERGE_STOP
-#define L3_MERGE_STOP 0
-#endif
 #ifndef L3_TILE_OCC
 #define L3_TILE_OCC 7
 #endif
@@ -654,7 +627,6 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         h = reinterpret_cast<uint16_t*>(R.bm[B_NX]); h[tid] = (uint16_t)m_nx;
     }
     __syncthreads();
-    L3_STOP_AFTER(1)
 
     // -- start-of-pre-token bits (one wave), digit runs that need more context than the halo holds
     if (wave == 0) {
@@ -723,7 +695,6 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     }
     const uint32_t n_pre = (uint32_t)vars[TV_NPRE];
     const u64* ST = R.bm[B_ST];
-    L3_STOP_AFTER(2)
 
     // -- compacted list of own pre-token starts (kListPer byte positions per thread; own_lo is 0 or kBack, so a
     //    thread's positions never straddle a 64-bit mask word)
@@ -755,7 +726,6 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         }
     }
     __syncthreads();
-    L3_STOP_AFTER(3)
 
     int32_t* res = reinterpret_cast<int32_t*>(&R.bm[B_LIVE][0]);
     int32_t* out0 = W.stream + tile * (uint64_t)kTileCap;
@@ -875,7 +845,6 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         }
     }
     __syncthreads();
-    L3_STOP_AFTER(4)
     const uint32_t shard = (uint32_t)(tile % kMissShards);
     // space in the shard's entry list: one returning atomic per tile, issued here and first needed after the
     // document loop below, so that its round trip overlaps with that loop
@@ -1138,10 +1107,6 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
         mi.len = 0; mi.tile = 0; mi.start = 0; mi.w[0] = mi.w[1] = mi.w[2] = mi.w[3] = 0;
         if (have) mi = W.miss_in[ei];
         const uint32_t len = mi.len;
-#if L3_MERGE_STOP == 1
-        if (have) W.miss_res[ei] = 1;
-        continue;
-#endif
         // ---- up to 16 bytes: every lane in its own 16-element slot
         {
             const bool act = have && len >= 1 && len <= 16;
@@ -1159,15 +1124,9 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
                     sy[j] = (uint32_t)byte_tok[bb[j]] | (nxt << 17) | (prv << 24);
                     pq[j] = (j < 15 && pp[j < 15 ? j : 0] != kNoPrio && (uint32_t)j < len) ? (pp[j < 15 ? j : 0] << 7) | (uint32_t)j : 0xFFFFFFFFu;
                 }
-#if L3_MERGE_STOP != 2
                 lane_merge<16>(T, sy, pq);
-#endif
             }
-#if L3_MERGE_STOP == 2 || L3_MERGE_STOP == 3
-            if (act) W.miss_res[ei] = 1 | ((uint64_t)(sy[0] & 0x1FFFFu) << 8);
-#else
             lane_finish(W, sy, act, ei, mi.tile, shard);
-#endif
         }
         // ---- 17..64 bytes: groups of 64 lanes, 64-element slots of the same arena
         const bool is_long = have && len > 16;

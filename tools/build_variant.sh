@@ -1,7 +1,8 @@
 #!/bin/bash
-# build_variant.sh NAME "FLAGS": builds tokenizer_amd/lib/variants/libl3hip_NAME.so with extra compile flags (A/B timing).
-# Use it with L3HIP_LIB=tokenizer_amd/lib/variants/libl3hip_NAME.so.  -DL3_DEBUG_FLAGS compiles in the
-# phase-skipping knobs tools/phase_timing.py needs (results are then wrong on purpose).  Delete variants after use.
+# build_variant.sh NAME "FLAGS": builds tokenizer_amd/lib/variants/libl3hip_NAME.so with extra compile flags for A/B
+# timing (tools/ab.sh NAME ... runs bench.py with each).  Knobs the sources honour: -DL3_TILE_BYTES (3840),
+# -DL3_TILE_OCC (7), -DL3_LOOK_U (4), -DL3_EMIT_OCC (6), -DL3_EMIT_PER (4), -DL3_MERGE_THREADS (256).
+# Delete the variants after use: they travel to the GPU box with every gpurun call.
 set -e
 cd "$(dirname "$0")/../tokenizer_amd/csrc"
 mkdir -p ../lib/variants ../lib/obj
