@@ -122,7 +122,7 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
         HIPCHK(c, c->w_status.ensure(sizeof(Status)));
         HIPCHK(c, hipMemset(c->w_status.p, 0, sizeof(Status)));
     }
-    uint64_t slow_min = n_bytes / 256 + 1024, miss_min = n_bytes / 64 / kMissShards + 256, pool_min = n_bytes / 8 + 4096,
+    uint64_t slow_min = n_bytes / 256 + 1024, miss_min = n_bytes / 2048 + 256, pool_min = n_bytes / 8 + 4096,
              scratch_min = 16ull << 20;
     if (c->slow_cap < slow_min) c->slow_cap = slow_min;
     if (c->miss_shard_cap < miss_min) c->miss_shard_cap = miss_min;

@@ -266,6 +266,13 @@ enum { B_ST = 0, B_SPS, B_INV, B_DS, B_LIVE, B_RS = B_LIVE, B_L, B_N, B_NL, B_SP
 
 constexpr int kResCap = (B_COUNT - B_LIVE) * (kWords + 2) * 2;  // stream items staged in LDS (the rest goes straight to HBM)
 constexpr int kRareCap = 512;
+// Short deferred pre-tokens are binned by length: shard = length class * 4 + (tile & 3), class = min(len, 16) - 1.
+// The 64 lanes of a merge wave then walk merge chains of about the same length (the chain of a wave is that of
+// its longest lane), which cut the merge kernel's time by a third; (tile & 3) spreads a class's atomics over
+// four counters.
+constexpr int kLenClasses = 16;
+static_assert(kLenClasses * 4 == kMissShards, "shard = length class * 4 + (tile & 3)");
+__device__ __forceinline__ uint32_t len_class(uint32_t len) { return (len < (uint32_t)kLenClasses ? len : (uint32_t)kLenClasses) - 1u; }
 struct TileLds {
     uint8_t b[kRegion + 16];
     u64 bm[B_COUNT][kWords + 2];
@@ -278,7 +285,7 @@ struct TileLds {
 };
 constexpr int kListPer = 16;
 static_assert(kListPer * kTileThreads >= kTile && 64 % kListPer == 0 && kBack % kListPer == 0, "list compaction geometry");
-enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NMISS, TV_NSLOW, TV_MISS0, TV_SLOW0, TV_NRARE, TV_ANYINV, TV_LASTE, TV_COUNT = 16 };
+enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NSLOW, TV_SLOW0, TV_NRARE, TV_ANYINV, TV_LASTE, TV_COUNT = 8 };
 
 struct TileSrc {  // byte source over the tile's LDS image, LOCAL coordinates [0, n)
     const TileLds* R;
@@ -492,6 +499,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     __shared__ __align__(16) TileLds R;
     __shared__ unsigned long long tmp64[8];
     __shared__ int vars[TV_COUNT];
+    __shared__ int ccnt[kLenClasses], cm0[kLenClasses];   // short deferred pre-tokens per length class; their first entry
 
     if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
@@ -510,7 +518,8 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     for (int i = tid; i < kWords + 2; i += kTileThreads) {
         R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0; R.bm[B_CE2][i] = 0; R.bm[B_CE3][i] = 0;
     }
-    if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; vars[TV_NRARE] = 0; vars[TV_ANYINV] = 0; }
+    if (tid == 0) { vars[TV_NSLOW] = 0; vars[TV_NRARE] = 0; vars[TV_ANYINV] = 0; }
+    if (tid < kLenClasses) ccnt[tid] = 0;
     {   // class table entry of byte value `tid` (state_machine.go:310-320 for ASCII: letters, Nd digits, unicode.IsSpace)
         const uint32_t v = (uint32_t)tid;
         const uint32_t f = v | 0x20u;
@@ -792,7 +801,10 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                     const bool hit = (sl[u].w[3] & ~0x1FFFFu) == (ln[u] << 17) && sl[u].w[0] == w0[u] && sl[u].w[1] == w1[u] && sl[u].w[2] == w2[u];
                     int32_t item;
                     if (hit) item = (int32_t)(sl[u].w[3] & 0x1FFFFu);
-                    else item = -2 - (int32_t)atomicAdd(&vars[TV_NMISS], 1);  // local ordinal (<= 12 valid bytes: a lane merges it)
+                    else {   // <= 12 valid bytes: a lane of the merge kernel does it; class and ordinal within the tile's class
+                        const uint32_t c = len_class(ln[u]);
+                        item = -2 - (int32_t)((c << 12) | (uint32_t)atomicAdd(&ccnt[c], 1));
+                    }
                     // deferred: the local ordinal for now, replaced below by the global entry index.  Staged in LDS (the
                     // bitmap rows that are dead by now); text of one- and two-byte pre-tokens can exceed it and goes
                     // straight to HBM
@@ -806,7 +818,8 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     const bool rare_all = (uint32_t)vars[TV_NRARE] > (uint32_t)kRareCap;   // uniform over the workgroup
     if (rare_all) {
         __syncthreads();
-        if (tid == 0) { vars[TV_NMISS] = 0; vars[TV_NSLOW] = 0; }
+        if (tid == 0) vars[TV_NSLOW] = 0;
+        if (tid < kLenClasses) ccnt[tid] = 0;
         __syncthreads();
     }
     {
@@ -838,21 +851,26 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                     }, (uint32_t)len);
                 }
                 if (id >= 0) item = id;
-                else if (e >= 0 && !inval && len <= kLaneMax) item = -2 - (int32_t)atomicAdd(&vars[TV_NMISS], 1);  // local ordinal
+                else if (e >= 0 && !inval && len <= kLaneMax) {
+                    const uint32_t c = len_class((uint32_t)len);
+                    item = -2 - (int32_t)((c << 12) | (uint32_t)atomicAdd(&ccnt[c], 1));
+                }
                 else item = -2 - (int32_t)(kSlowBase + (uint32_t)atomicAdd(&vars[TV_NSLOW], 1));
             }
             if (k < (uint32_t)kResCap) res[k] = item; else out0[k] = item;
         }
     }
     __syncthreads();
-    const uint32_t shard = (uint32_t)(tile % kMissShards);
-    // space in the shard's entry list: one returning atomic per tile, issued here and first needed after the
-    // document loop below, so that its round trip overlaps with that loop
-    uint32_t m0_r = 0, s0_r = 0, nm_r = 0, ns_r = 0;
-    if (tid == 0) {
-        nm_r = (uint32_t)vars[TV_NMISS]; ns_r = (uint32_t)vars[TV_NSLOW];
-        m0_r = nm_r ? atomicAdd(&W.status->shard[shard].miss_count, nm_r) : 0u;
-        s0_r = ns_r ? atomicAdd(&W.status->slow_count, ns_r) : 0u;
+    // space in the entry lists: one returning atomic per length class the tile uses (lanes 0..15) and one for the slow
+    // list (lane 16), issued here and first needed after the document loop below, so that the round trip overlaps
+    const uint32_t sub = (uint32_t)(tile & 3u);
+    uint32_t m0_r = 0, nm_r = 0;
+    if (tid < kLenClasses) {
+        nm_r = (uint32_t)ccnt[tid];
+        m0_r = nm_r ? atomicAdd(&W.status->shard[(uint32_t)tid * 4u + sub].miss_count, nm_r) : 0u;
+    } else if (tid == kLenClasses) {
+        nm_r = (uint32_t)vars[TV_NSLOW];
+        m0_r = nm_r ? atomicAdd(&W.status->slow_count, nm_r) : 0u;
         W.tile_items[tile] = n_pre;
     }
     // -- stream index of the first item of every document that starts in this tile
@@ -872,15 +890,16 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             W.doc_item[d] = item;
         }
     }
-    if (tid == 0) {
+    if (tid < kLenClasses) {
         if (nm_r && (uint64_t)m0_r + nm_r > W.miss_shard_cap) atomicOr(&W.status->flags, kOvfMiss);
-        if (ns_r && (uint64_t)s0_r + ns_r > W.slow_cap) atomicOr(&W.status->flags, kOvfSlow);
-        vars[TV_MISS0] = (int)m0_r;
-        vars[TV_SLOW0] = (int)s0_r;
+        cm0[tid] = (int)m0_r;
+    } else if (tid == kLenClasses) {
+        if (nm_r && (uint64_t)m0_r + nm_r > W.slow_cap) atomicOr(&W.status->flags, kOvfSlow);
+        vars[TV_SLOW0] = (int)m0_r;
     }
     __syncthreads();
     {
-        const uint32_t m0 = (uint32_t)vars[TV_MISS0], s0 = (uint32_t)vars[TV_SLOW0];
+        const uint32_t s0 = (uint32_t)vars[TV_SLOW0];
         int32_t* out = W.stream + tile * (uint64_t)kTileCap;
         // Staged items first, then (rare) those past the staging array, which every thread re-reads from its own
         // stores.  Keep the two loops written out like this: variants of this pass that used a shared lambda, or one
@@ -910,8 +929,9 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                     }
                     ei += kSlowBase;
                 } else {
-                    const uint64_t li = (uint64_t)m0 + ord;
-                    ei = shard * W.miss_shard_cap + li;
+                    const uint32_t c = ord >> 12;
+                    const uint64_t li = (uint64_t)(uint32_t)cm0[c] + (ord & 4095u);
+                    ei = (uint64_t)(c * 4u + sub) * W.miss_shard_cap + li;
                     if (li < W.miss_shard_cap) {
                         MissIn mi;
                         mi.start = g_lo + (uint64_t)s;
@@ -955,8 +975,9 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                     }
                     ei += kSlowBase;
                 } else {
-                    const uint64_t li = (uint64_t)m0 + ord;
-                    ei = shard * W.miss_shard_cap + li;
+                    const uint32_t c = ord >> 12;
+                    const uint64_t li = (uint64_t)(uint32_t)cm0[c] + (ord & 4095u);
+                    ei = (uint64_t)(c * 4u + sub) * W.miss_shard_cap + li;
                     if (li < W.miss_shard_cap) {
                         MissIn mi;
                         mi.start = g_lo + (uint64_t)s;
@@ -1094,13 +1115,30 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
     if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x;
     for (int i = tid; i < 256; i += kMergeThreads) byte_tok[i] = T.byte_tok[i];
-    const uint32_t shard = blockIdx.x % kMissShards;
-    uint64_t n_ent = W.status->shard[shard].miss_count;
-    if (n_ent > W.miss_shard_cap) n_ent = W.miss_shard_cap;
-    const uint64_t stride = (uint64_t)(gridDim.x / kMissShards) * kMergeThreads;
+    // Windows of 256 entries over all shards, longest length class first (its windows take longest); workgroup b
+    // takes windows b, b + gridDim.x, ...
+    __shared__ uint32_t win0[kMissShards + 1];   // first window of shard 63 - i
+    if (tid < 64) {
+        uint64_t c = W.status->shard[kMissShards - 1 - tid].miss_count;
+        if (c > W.miss_shard_cap) c = W.miss_shard_cap;
+        const uint32_t nw = (uint32_t)((c + kMergeThreads - 1) / kMergeThreads);
+        const uint32_t inc = wave_iscan(nw);
+        win0[tid] = inc - nw;
+        if (tid == 63) win0[kMissShards] = inc;
+    }
     __syncthreads();
+    const uint32_t n_win = win0[kMissShards];
 #pragma unroll 1
-    for (uint64_t chunk = (uint64_t)(blockIdx.x / kMissShards) * kMergeThreads; chunk < n_ent; chunk += stride) {
+    for (uint32_t w = blockIdx.x; w < n_win; w += gridDim.x) {
+        uint32_t lo = 0, hi = kMissShards - 1;   // last i with win0[i] <= w (empty shards share a value: take the last)
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (win0[mid] <= w) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t shard = kMissShards - 1 - lo;
+        uint64_t n_ent = W.status->shard[shard].miss_count;
+        if (n_ent > W.miss_shard_cap) n_ent = W.miss_shard_cap;
+        const uint64_t chunk = (uint64_t)(w - win0[lo]) * kMergeThreads;
         const bool have = chunk + tid < n_ent;
         const uint64_t ei = shard * W.miss_shard_cap + chunk + tid;
         MissIn mi;
@@ -1919,10 +1957,9 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         L3_LAUNCH_CHECK();
         L3_EV(kEvTile);
         {
-            uint64_t per = (W.miss_shard_cap + kMergeThreads - 1) / kMergeThreads;  // workgroups per shard
-            if (per > 32) per = 32;
-            if (per == 0) per = 1;
-            const uint64_t mgrid = per * kMissShards;
+            uint64_t mgrid = ((W.miss_shard_cap + kMergeThreads - 1) / kMergeThreads) * kMissShards;  // windows at most
+            if (mgrid > 2048) mgrid = 2048;
+            if (mgrid == 0) mgrid = 1;
             hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)mgrid), dim3(kMergeThreads), 0, stream, T, W, A);
             L3_LAUNCH_CHECK();
         }
