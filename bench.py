@@ -71,11 +71,19 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     flags = capi.L3_BOS | capi.L3_EOS
 
+    # the call of one step, with its arguments marshalled once: the host side of a step is in the timed region too
+    import ctypes as C
+    n_out = C.c_uint64(0)
+    call_args = (ctx.h, C.c_void_p(d_text.data_ptr()), C.c_uint64(n_bytes), C.c_void_p(d_off.data_ptr()), C.c_uint64(n_docs),
+                 C.c_uint32(flags), C.c_void_p(d_out.data_ptr()), C.c_uint64(out_cap), C.c_void_p(d_out_off.data_ptr()),
+                 C.byref(n_out), C.c_void_p(stream))
+    encode = ctx.lib.l3_encode_batch_device
+
     def step():
-        rc, n = ctx.encode_batch_device(d_text.data_ptr(), n_bytes, d_off.data_ptr(), n_docs, flags, d_out.data_ptr(),
-                                        out_cap, d_out_off.data_ptr(), stream)
+        rc = encode(*call_args)
         if rc != capi.L3_OK:
             raise RuntimeError("l3_encode_batch_device failed: %d" % rc)
+        n = n_out.value
         if dist is not None:  # global offsets: per-shard counts over RCCL (16 B per rank)
             counts[0] = n
             counts[1] = n_docs

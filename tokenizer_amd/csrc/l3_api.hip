@@ -178,6 +178,11 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false));
         HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
+        if (c->h_status->generic_tiles && !(c->h_status->flags & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch | kOvfOut))) {
+            // tiles with empty documents or token floods: the generic scatter, launched only when the fast one asks
+            HIPCHK(c, launch_emit_generic(W, A, stream));
+            HIPCHK(c, hipStreamSynchronize(stream));
+        }
         HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream));
         c->clear_pending = true;
         c->clear_stream = stream;

@@ -55,7 +55,8 @@ enum : uint32_t {
 struct Status {
     uint32_t slow_count;        // entries appended so far (may exceed capacity: overflow)
     uint32_t flags;             // kOvf* / kBadOffsets
-    uint32_t pad0, pad1;
+    uint32_t generic_tiles;     // tiles the fast emit kernel left to the generic one (the host launches it only then)
+    uint32_t pad1;
     unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
     unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the scan)
     unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)
@@ -128,6 +129,8 @@ enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvEmit, kEvC
 // the caller enlarged the output buffer).
 hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream,
                          hipEvent_t* ev, bool emit_only);
+// The second half of the final scatter, for the tiles the fast emit kernel flagged (Status::generic_tiles > 0).
+hipError_t launch_emit_generic(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
 // Decode: ids -> bytes (tokenizer.go:339-354).  Two passes: lengths+scan, then copy.
 hipError_t launch_decode(const uint32_t* tok_off, const uint8_t* tok_bytes, int n_tokens, const int32_t* ids,
                          const uint64_t* id_off, uint64_t n_seqs, uint8_t* out, uint64_t out_cap,

@@ -1650,7 +1650,7 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
     const int32_t* in = W.stream + tile * (uint64_t)kTileCap;
     const uint64_t n_tdocs = d_hi - d_lo;
     if (n_tok + (n_tdocs + 1) * be > (uint64_t)kStage || n_tdocs > (uint64_t)n_items + 1) {
-        if (tid == 0) W.tile_flag[tile] = 1;
+        if (tid == 0) { W.tile_flag[tile] = 1; atomicAdd(&W.status->generic_tiles, 1u); }
         return;
     }
     if (tid < kDmaskWords) dmask[tid] = 0;
@@ -1669,7 +1669,7 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
     }
     __syncthreads();
     if (s_generic) {
-        if (tid == 0) W.tile_flag[tile] = 1;
+        if (tid == 0) { W.tile_flag[tile] = 1; atomicAdd(&W.status->generic_tiles, 1u); }
         return;
     }
     if (tid == 0) W.tile_flag[tile] = 0;
@@ -1943,6 +1943,14 @@ __global__ __launch_bounds__(256) void decode_copy_kernel(const uint32_t* tok_of
         }                                                                 \
     } while (0)
 
+hipError_t launch_emit_generic(const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
+    const uint64_t n_tiles = num_tiles(A.n_bytes);
+    hipLaunchKernelGGL(emit_generic_kernel, dim3((uint32_t)((n_tiles + kGenericPer - 1) / kGenericPer)), dim3(kTileThreads), 0,
+                       stream, W, A, n_tiles);
+    L3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream, hipEvent_t* ev,
                          bool emit_only) {
     const uint64_t n_tiles = num_tiles(A.n_bytes);
@@ -1978,9 +1986,10 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
     }
     hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)n_tiles), dim3(kTileThreads), 0, stream, W, A);
     L3_LAUNCH_CHECK();
-    hipLaunchKernelGGL(emit_generic_kernel, dim3((uint32_t)((n_tiles + kGenericPer - 1) / kGenericPer)), dim3(kTileThreads), 0,
-                       stream, W, A, n_tiles);
-    L3_LAUNCH_CHECK();
+    if (emit_only) {   // the re-run after the caller enlarged its buffer: the flags of the first run are gone
+        hipError_t e_ = launch_emit_generic(W, A, stream);
+        if (e_ != hipSuccess) return e_;
+    }
     L3_EV(kEvEmit);
     return hipSuccess;
 }
