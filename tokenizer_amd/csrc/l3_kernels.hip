@@ -349,7 +349,7 @@ __device__ __forceinline__ Seg wave_seg_escan(Seg v) {
 // `edge_digits`: number of Nd runes immediately before the tile start when a digit run fills the
 // whole look-behind halo (only read when `use_edge`).  Writes bm[B_ST], bm[B_N], bm[B_CONTN], wpre[];
 // returns flags: bit0 a digit run reaches the region start (edge count needed), bit1 multi-byte digits.
-__device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_hi, int eval_hi, bool region_at_text_start,
+__device__ __noinline__ uint32_t compute_starts(TileLds& R, int n, int own_lo, int own_hi, int eval_hi, bool region_at_text_start,
                                                 bool use_edge, uint32_t edge_digits, int* n_pre_out) {
     const int w = lane_id();
     const bool act = w < kWords;
@@ -364,10 +364,19 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
     const u64 APOS = L3_LD(B_APOS) & nspb, CE2 = L3_LD(B_CE2), CE3 = L3_LD(B_CE3);
     const u64 NX = L3_LD(B_NX) & nspb;
     const u64 cont = ~RS;
+    // Does the region hold any byte that is not a rune start (continuation bytes, special-token bodies)?  Pure
+    // ASCII text does not, and the three smearing loops below (each three rounds of wave shuffles) have nothing
+    // to do: uniform over the wave, so they are skipped.
+    bool multi;
+    {
+        const int lo = w * 64;
+        const u64 rng = n <= lo ? 0ull : (n >= lo + 64 ? ~0ull : (1ull << (n - lo)) - 1ull);
+        multi = __ballot(act && (cont & rng) != 0) != 0;
+    }
     // class of the rune that CONTAINS each byte (classes smeared over continuation bytes)
     u64 sL = L, sN = N, sWS = WS, sP = P;
 #pragma unroll
-    for (int it = 0; it < 3; it++) {
+    for (int it = 0; it < 3 && multi; it++) {
         uint32_t t = (uint32_t)(sL >> 63) | ((uint32_t)(sN >> 63) << 1) | ((uint32_t)(sWS >> 63) << 2) | ((uint32_t)(sP >> 63) << 3);
         uint32_t u = up32(t);
         sL |= ((sL << 1) | (u & 1u)) & cont;
@@ -393,7 +402,7 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
     // punctuation rune preceded (in its segment) by punctuation or ' ': a letter after it starts a token
     u64 sQ = P & ~SEG & (p_P | p_SP);
 #pragma unroll
-    for (int it = 0; it < 3; it++) {
+    for (int it = 0; it < 3 && multi; it++) {
         uint32_t u = up32((uint32_t)(sQ >> 63));
         sQ |= ((sQ << 1) | (u & 1u)) & cont;
     }
@@ -420,7 +429,7 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int own_lo, int own_
         const u64 NWS = RS & ~SEG & ~Wany;
         B = (NWS >> 1) | ((u64)(dn32((uint32_t)NWS) & 1u) << 63);
 #pragma unroll
-        for (int it = 0; it < 3; it++) {
+        for (int it = 0; it < 3 && multi; it++) {
             u64 x = B & cont;
             B |= (x >> 1) | ((u64)(dn32((uint32_t)x) & 1u) << 63);
         }
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     // -- start-of-pre-token bits (one wave), digit runs that need more context than the halo holds
     if (wave == 0) {
         int n_pre = 0;
-        uint32_t fl = compute_starts(R, own_lo, own_hi, eval_hi, g_lo == 0, false, 0u, &n_pre);
+        uint32_t fl = compute_starts(R, n, own_lo, own_hi, eval_hi, g_lo == 0, false, 0u, &n_pre);
         if (lane == 0) {
             vars[TV_NPRE] = n_pre;
             vars[TV_MB] = (fl & 2u) ? 1 : 0;
@@ -663,7 +672,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         if (!mbd) {
             if (wave == 0) {
                 int n_pre = 0;
-                compute_starts(R, own_lo, own_hi, eval_hi, g_lo == 0, true, edge, &n_pre);
+                compute_starts(R, n, own_lo, own_hi, eval_hi, g_lo == 0, true, edge, &n_pre);
                 if (lane == 0) vars[TV_NPRE] = n_pre;
             }
         } else if (tid == 0) {
