@@ -1736,8 +1736,12 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
             if (i < n_items) {
                 if (item[j] >= 0) {
                     stg[rel] = item[j];
+                } else if (inl[j]) {   // up to three tokens inside the result word: straight-line stores
+                    stg[rel] = (int32_t)(poff[j] & 0x1FFFFu);
+                    if (cnt[j] > 1) stg[rel + 1] = (int32_t)((poff[j] >> 17) & 0x1FFFFu);
+                    if (cnt[j] > 2) stg[rel + 2] = (int32_t)((poff[j] >> 34) & 0x1FFFFu);
                 } else if (cnt[j] <= 64) {
-                    for (uint32_t k = 0; k < cnt[j]; k++) stg[rel + k] = deferred_token(W, poff[j], inl[j], k);
+                    for (uint32_t k = 0; k < cnt[j]; k++) stg[rel + k] = W.pool[poff[j] + k];
                 } else {
                     const uint32_t qi = atomicAdd(&q_n, 1u);
                     if (qi < kEmitQueue) { q_rel[qi] = rel; q_item[qi] = item[j]; }
