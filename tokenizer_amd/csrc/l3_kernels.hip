@@ -510,7 +510,6 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     __shared__ int vars[TV_COUNT];
     __shared__ int ccnt[kLenClasses], cm0[kLenClasses];   // short deferred pre-tokens per length class; their first entry
 
-    if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const uint64_t tile = blockIdx.x;
     const uint64_t t_lo = tile * (uint64_t)kTile;
@@ -521,9 +520,25 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     const int own_lo = (int)(t_lo - g_lo), own_hi = (int)(t_hi - g_lo);
     const bool hard = g_hi == A.n_bytes;
     const int eval_hi = hard ? n : n - kEvalSlack;
-    const uint32_t d0 = W.tile_doc0[tile];
 
-    // -- stage bytes (16 per thread), clear what is accumulated with atomics
+    // -- the three loads a tile starts with are requested together (its own 16 bytes of text, its first document, the
+    //    status word); the LDS set-up below runs while they are in flight
+    const int c0 = tid * 16;            // region bytes [c0, c0 + 16) are classified by this thread
+    const bool cls_thread = tid < kRegion / 16;
+    uint32_t xw[4] = {0, 0, 0, 0};
+    if (cls_thread && c0 < n) {
+        const uint8_t* srcp = A.text + g_lo + c0;
+        if (c0 + 16 <= n && (((uintptr_t)srcp) & 15u) == 0) {
+            const uint4 v = *reinterpret_cast<const uint4*>(srcp);
+            xw[0] = v.x; xw[1] = v.y; xw[2] = v.z; xw[3] = v.w;
+        } else {
+            for (int k = 0; k < 16 && c0 + k < n; k++) xw[k >> 2] |= (uint32_t)srcp[k] << ((k & 3) * 8);
+        }
+    }
+    const uint32_t d0 = W.tile_doc0[tile];
+    const uint32_t status_flags = W.status->flags;
+
+    // -- clear what is accumulated with atomics
     for (int i = tid; i < kWords + 2; i += kTileThreads) {
         R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0; R.bm[B_CE2][i] = 0; R.bm[B_CE3][i] = 0;
     }
@@ -542,18 +557,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         const uint32_t clt = v == '<' ? 1u : 0u;
         R.ctab[tid] = make_uint4(asc | (cl << 16), cn | (cnl << 16), csp | (cws << 16), cap | (clt << 16));
     }
-    const int c0 = tid * 16;            // region bytes [c0, c0 + 16) are classified by this thread
-    const bool cls_thread = tid < kRegion / 16;
-    uint32_t xw[4] = {0, 0, 0, 0};
-    if (cls_thread && c0 < n) {
-        const uint8_t* srcp = A.text + g_lo + c0;
-        if (c0 + 16 <= n && (((uintptr_t)srcp) & 15u) == 0) {
-            const uint4 v = *reinterpret_cast<const uint4*>(srcp);
-            xw[0] = v.x; xw[1] = v.y; xw[2] = v.z; xw[3] = v.w;
-        } else {
-            for (int k = 0; k < 16 && c0 + k < n; k++) xw[k >> 2] |= (uint32_t)srcp[k] << ((k & 3) * 8);
-        }
-    }
+    if (status_flags & kBadOffsets) return;   // (uniform; tile_doc0 is only trustworthy without it)
     if (cls_thread) *reinterpret_cast<uint4*>(&R.b[c0]) = make_uint4(xw[0], xw[1], xw[2], xw[3]);
     if (tid == 0) *reinterpret_cast<uint4*>(&R.b[kRegion]) = make_uint4(0, 0, 0, 0);
     __syncthreads();
