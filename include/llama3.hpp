@@ -8,6 +8,7 @@
 //   Tokenizer::AppendTokens                   tokenizer.go:276-330
 //   Tokenizer::Decode / DecodeBytes           tokenizer.go:333-354
 //   Tokenizer::GetSpecialTokenID              tokenizer.go:357-368  (ErrInvalidToken / ErrTokenNotFound)
+//   Tokenizer::OptimisticCount                tokenizer.go:370-417
 //   Tokenizer::VocabSize / PreTokenize        tokenizer.go:420-422,490-504
 //   Tokenizer::EncodeBatch                    new, additive: the batched hot path
 //   scanner::Tokenizer, scanner::New/NewWithOptions, Scanner::Scan/Token/Text/Err
@@ -351,6 +352,45 @@ class Tokenizer : public scanner::Tokenizer {
             return 0;
         }
         return id;
+    }
+    // OptimisticCount (tokenizer.go:370-417): the token count when anything of the shape <|[a-zA-Z0-9_]+|>
+    // (internal/tokens/special.go:15) counts as ONE token, plus BOS and EOS.  The pieces between those matches are
+    // pre-tokenized and merged as plain text -- one batch call, a document per piece, L3_NO_SPECIAL.  -1 on a device
+    // failure (LastError() says which).
+    int OptimisticCount(const std::string& text) {
+        std::vector<uint64_t> off{0};
+        std::string plain;
+        size_t matches = 0, piece_start = 0, i = 0;
+        const size_t n = text.size();
+        auto word = [](unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; };
+        while (i + 1 < n) {
+            if (text[i] == '<' && text[i + 1] == '|') {
+                size_t j = i + 2;
+                while (j < n && word((unsigned char)text[j])) j++;
+                if (j > i + 2 && j + 1 < n && text[j] == '|' && text[j + 1] == '>') {   // leftmost match, then on after it
+                    if (i > piece_start) { plain.append(text, piece_start, i - piece_start); off.push_back(plain.size()); }
+                    matches++;
+                    i = j + 2;
+                    piece_start = i;
+                    continue;
+                }
+            }
+            i++;
+        }
+        if (n > piece_start) { plain.append(text, piece_start, n - piece_start); off.push_back(plain.size()); }
+        uint64_t n_tok = 0;
+        if (off.size() > 1) {
+            std::vector<int32_t> ids(plain.size() + 64);
+            std::vector<uint64_t> id_off(off.size());
+            for (;;) {
+                int rc = l3_encode_batch(ctx_, (const uint8_t*)plain.data(), off.data(), off.size() - 1, L3_NO_SPECIAL, ids.data(),
+                                         ids.size(), id_off.data(), &n_tok);
+                if (rc == L3_E_OUTPUT_CAP) { ids.resize((size_t)n_tok); continue; }
+                if (rc != L3_OK) { last_.kind = ErrKind::Device; last_.op = "optimistic count"; last_.detail = l3_last_error(ctx_); return -1; }
+                break;
+            }
+        }
+        return (int)(n_tok + matches + 2);
     }
     int VocabSize() const { return l3_vocab_size(ctx_); }  // tokenizer.go:420-422
     // PreTokenize (tokenizer.go:490-506): the pieces of pretokenizer.Tokenize(text) -- which knows no special

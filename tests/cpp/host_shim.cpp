@@ -94,6 +94,7 @@ int l3h_special(void* h, const char* name, int* err_kind) {
     return id;
 }
 int l3h_vocab_size(void* h) { return ((Tokenizer*)h)->VocabSize(); }
+int l3h_optimistic_count(void* h, const char* text, long long n) { return ((Tokenizer*)h)->OptimisticCount(std::string(text, (size_t)n)); }
 // pieces concatenated into buf with their cumulative ends; raw = before the byte-level mapping
 long long l3h_pretokenize(void* h, const char* text, long long n, int raw, uint8_t* buf, long long buf_cap, long long* ends,
                           long long cap) {

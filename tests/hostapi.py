@@ -39,6 +39,8 @@ def load():
         L.l3h_special.argtypes = [_P, C.c_char_p, C.POINTER(C.c_int)]
         L.l3h_vocab_size.restype = C.c_int
         L.l3h_vocab_size.argtypes = [_P]
+        L.l3h_optimistic_count.restype = C.c_int
+        L.l3h_optimistic_count.argtypes = [_P, C.c_char_p, _LL]
         L.l3h_pretokenize.restype = _LL
         L.l3h_pretokenize.argtypes = [_P, C.c_char_p, _LL, C.c_int, _P, _LL, _P, _LL]
         L.l3h_scan.restype = _LL
@@ -122,6 +124,9 @@ class Tokenizer:
 
     def vocab_size(self):
         return self.L.l3h_vocab_size(self.h)
+
+    def optimistic_count(self, text: bytes):
+        return self.L.l3h_optimistic_count(self.h, text, len(text))
 
     def pretokenize(self, text: bytes, raw=False):
         cap = len(text) + 1

@@ -202,6 +202,25 @@ def test_pretokenize(tok, oracle):
     assert tok.pretokenize("Hello 世界".encode()) == ["Hello".encode(), "Ġä¸ĸçķĮ".encode()]
 
 
+@pytest.mark.gpu
+def test_optimistic_count(tok, oracle):
+    # tokenizer_test.go:408-445 (lower bounds) and tokenizer.go:370-417 restated with the oracle: anything shaped like a
+    # special token counts one, the text between is plain text, BOS and EOS always count
+    import re
+    pat = re.compile(rb"<\|[a-zA-Z0-9_]+\|>")
+
+    def expect(text):
+        pieces = pat.split(text)
+        return 2 + len(pat.findall(text)) + sum(len(oracle.encode(p, False, False)) for p in pieces if p)
+
+    for text, lo in [(b"Hello world", 3), (b"<|begin_of_text|>Hello<|end_of_text|>", 4), (b"<|custom_token|>Hello<|another_custom|>", 5)]:
+        got = tok.optimistic_count(text)
+        assert got >= lo and got == expect(text)
+    for text in [b"", b"<|x|>", b"<|x|><|y_2|>", b"a<||>b", b"<|not closed", b"<|a b|>", b"<|<|ok|>|>", b"x<|a|", b"tail <|",
+                 "名前<|eot_id|>は 🦙 12345<|made_up|>\n\n".encode(), b"<|a|>" * 50 + b" end", b"\xff<|q|>\xfe"]:
+        assert tok.optimistic_count(text) == expect(text), text
+
+
 def _expected_scan(oracle, data, read_sizes=(), buf_size=4096, max_buffer=1 << 20, opts=NO):
     """What the reference scanner yields: Encode per chunk, BOS on the first, EOS once EOF is known."""
     out = []
