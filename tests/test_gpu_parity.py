@@ -75,6 +75,23 @@ def test_readme_vectors(ctx):
     assert ctx.encode_docs([b"Hello world!"])[0] == [128000, 9906, 1917, 0, 128001]
 
 
+def test_c1_inputs_against_oracle(ctx, oracle):
+    # the 476 generated and 60 literal inputs of the reference's differential tests, one document each
+    from tests import c1_inputs
+    docs = c1_inputs.generated() + c1_inputs.comparison()
+    for bos, eos in ((True, True), (False, False)):
+        check_batch(ctx, oracle, docs, bos, eos, "C1 inputs")
+    from tokenizer_amd import capi
+    text, off = capi.pack_docs(docs)
+    kinds = ctx.pretokenize_batch(text, off)
+    o = off.astype(np.int64)
+    for i, d in enumerate(docs):
+        st, kd = oracle.split_document(d)
+        k = kinds[o[i]:o[i + 1]]
+        got = np.nonzero(k)[0].tolist()
+        assert got == st and (k[got] - 1).tolist() == kd, (i, d)
+
+
 def test_pretokenize_kats(ctx, oracle):
     from tokenizer_amd import capi
     docs = [bytes.fromhex(c["input"]) for c in PRE]

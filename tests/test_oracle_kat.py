@@ -68,3 +68,17 @@ def test_divergences_from_official_regex(oracle):
     assert oracle.pretokenize_strings(b"\n \n") == [b"\n", b" \n"]
     assert oracle.encode(b"\n \n", False, False) == [198, 720]
     assert oracle.encode(b"a\xffb", False, False) == oracle.encode("a�b".encode(), False, False)
+
+
+def test_c1_inputs_round_trip_and_cover_their_text(oracle):
+    """the reference's differential-test inputs (no expected values exist for them).  Properties every
+    correct encoding has: decode(encode(x)) == x for valid UTF-8, the pre-tokens tile the text, and BOS/EOS only
+    frame the ids."""
+    from tests import c1_inputs
+    inputs = c1_inputs.generated() + c1_inputs.comparison()
+    assert len(c1_inputs.generated()) == 476 and len(c1_inputs.comparison()) == 60
+    for x in inputs:
+        ids = oracle.encode(x, False, False)
+        assert oracle.decode(ids) == x, x
+        assert oracle.encode(x, True, True) == [128000] + ids + [128001]
+        assert b"".join(oracle.pretokenize_strings(x)) == x

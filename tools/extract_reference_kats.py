@@ -197,8 +197,22 @@ def extract_encode():
     return enc, dec, large
 
 
+def extract_comparison_inputs():
+    """the literal input strings of comparison_test.go (its expected values come from a JS tokenizer the reference
+    does not ship, so these are inputs only: the GPU path is compared with the oracle on them)"""
+    src = open(os.path.join(REF, "llama3", "comparison_test.go"), encoding="utf-8").read()
+    i = src.index("testInputs := []string{")
+    i = src.index("[]string{", i)
+    vals, _ = parse_string_slice(src, i)
+    return [hexs(v) for v in vals]
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    cmp_inputs = extract_comparison_inputs()
+    json.dump({"source": "llama3/comparison_test.go:84-164 (inputs only)", "inputs": cmp_inputs},
+              open(os.path.join(OUT, "ref_comparison_inputs.json"), "w"), indent=0)
+    print("comparison inputs:", len(cmp_inputs))
     pre, classes = extract_pretokenize()
     enc, dec, large = extract_encode()
     # documentation KATs (README.md:113-114, llama3/README.md:44)
