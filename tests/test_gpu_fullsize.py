@@ -66,3 +66,54 @@ def test_c4_pathological_1mib(ctx, oracle):
         _same(ctx, oracle, t, o, threads=1)
     t, o = capi.pack_docs(docs)
     _same(ctx, oracle, t, o)
+
+
+def test_host_batches_in_pieces(ctx, oracle):
+    """l3_encode_batch moves batches of >= 16 MiB in pieces of whole documents (overlapped copies): same result as
+    the device-pointer entry point in one pass, ragged documents included, and the capacity protocol still holds."""
+    import ctypes as C
+
+    import torch
+
+    from tokenizer_amd import capi
+    rng = np.random.default_rng(5)
+    base, boff = corpora.english(40000, 1024)
+    # ragged: cut the same text at random places instead (documents of 1 B .. 64 KiB, some empty)
+    cuts = np.unique(np.concatenate([[0, base.size], rng.integers(0, base.size, 3000), np.arange(0, 1 << 22, 97)]))
+    off = np.sort(np.concatenate([cuts, cuts[100:200]])).astype(np.uint64)   # duplicates = empty documents
+    # page-locked caller buffers select the path in pieces
+    p_text = torch.empty(base.size, dtype=torch.uint8).pin_memory()
+    p_text.numpy()[:] = base
+    p_out = torch.empty(base.size + 2 * (off.size - 1) + 64, dtype=torch.int32).pin_memory()
+    p_off = np.empty(off.size, dtype=np.uint64)
+    n_p = C.c_uint64(0)
+    rc = ctx.lib.l3_encode_batch(ctx.h, p_text.numpy().ctypes.data, off.ctypes.data, off.size - 1, 3, p_out.numpy().ctypes.data,
+                                 p_out.numel(), p_off.ctypes.data, C.byref(n_p))
+    assert rc == capi.L3_OK
+    tok, toff = p_out.numpy()[:n_p.value].copy(), p_off
+    tok1, toff1 = ctx.encode_batch(base, off, True, True)   # pageable buffers: one pass
+    assert np.array_equal(tok1, tok) and np.array_equal(toff1, toff)
+    d_text = torch.from_numpy(base).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    n_docs = off.size - 1
+    d_out = torch.empty(base.size + 2 * n_docs + 64, dtype=torch.int32, device="cuda")
+    d_oo = torch.empty(n_docs + 1, dtype=torch.int64, device="cuda")
+    rc, n = ctx.encode_batch_device(d_text.data_ptr(), base.size, d_off.data_ptr(), n_docs, 3, d_out.data_ptr(), d_out.numel(),
+                                    d_oo.data_ptr())
+    assert rc == capi.L3_OK and n == tok.size
+    assert np.array_equal(d_oo.cpu().numpy().astype(np.uint64), toff)
+    assert np.array_equal(d_out[:n].cpu().numpy(), tok)
+    e_tok, e_off = oracle.encode_batch(base[:1 << 22], off[off <= (1 << 22)], True, True, threads=16)   # and a slice against the oracle
+    k = e_off.size - 1
+    assert np.array_equal(toff[:k + 1], e_off) and np.array_equal(tok[:int(e_off[-1])], e_tok)
+    # capacity protocol
+    with pytest.raises(capi.L3Error) as ei:
+        ctx.encode_batch(base, off, True, True, out_cap=1000)
+    assert ei.value.code == capi.L3_E_OUTPUT_CAP
+    ooff = np.empty(n_docs + 1, dtype=np.uint64)
+    need = C.c_uint64(0)
+    rc = ctx.lib.l3_encode_batch(ctx.h, p_text.numpy().ctypes.data, off.ctypes.data, n_docs, 3, p_out.numpy().ctypes.data, 16,
+                                 ooff.ctypes.data, C.byref(need))   # in pieces
+    assert rc == capi.L3_E_OUTPUT_CAP and need.value == tok.size and np.array_equal(ooff, toff)
+    tok2, toff2 = ctx.encode_batch(base, off, True, True, out_cap=tok.size)
+    assert np.array_equal(tok2, tok) and np.array_equal(toff2, toff)

@@ -51,6 +51,11 @@ struct l3_ctx {
     Status* h_status = nullptr;          // pinned
     unsigned long long* h_total = nullptr;  // pinned
     hipStream_t stream = nullptr;
+    // host-fed batches in pieces: upload stream, download stream, two output buffers in turn
+    hipStream_t stream_in = nullptr, stream_out = nullptr;
+    DevBuf p_out[2], p_outoff[2];
+    hipEvent_t ev_in[8] = {}, ev_out[2] = {};
+    bool have_pipe = false;
     hipEvent_t ev[kEvCount] = {};
     bool have_events = false, profiling = false;
     float last_ms[kEvCount] = {};
@@ -306,6 +311,12 @@ void l3_destroy(l3_ctx* c) {
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->have_events)
         for (int i = 0; i < kEvCount; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->have_pipe) {
+        for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev_in[i]);
+        for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_out[i]); c->p_out[i].release(); c->p_outoff[i].release(); }
+        (void)hipStreamDestroy(c->stream_in);
+        (void)hipStreamDestroy(c->stream_out);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -338,6 +349,106 @@ int l3_encode_batch_device(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, c
     return rc;
 }
 
+// page-locked host memory (hipHostMalloc / hipHostRegister), which the copy engines reach directly
+static bool is_pinned(const void* p) {
+    hipPointerAttribute_t attr;
+    if (!p || hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// Host-fed batches of >= 16 MiB in page-locked buffers go through the GPU in up to eight pieces of whole documents: the upload of piece k + 1
+// and the download of piece k - 1 run on streams of their own while piece k is encoded, so a call costs about the
+// longer of the two PCIe directions instead of upload + kernels + download.  Results are identical to one pass:
+// documents are independent, and the per-piece offsets are shifted on the host.
+static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                               int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok) {
+    const uint64_t n_bytes = doc_off[n_docs];
+    if (!c->have_pipe) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
+        for (int i = 0; i < 8; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+        c->have_pipe = true;
+    }
+    uint64_t want = n_bytes >> 23;   // pieces of about 8 MiB
+    const int S = (int)(want < 2 ? 2 : (want > 8 ? 8 : want));
+    uint64_t d_lo[9];
+    d_lo[0] = 0;
+    for (int k = 1; k < S; k++) {   // first document that starts at or after k / S of the bytes
+        const uint64_t target = n_bytes / (uint64_t)S * (uint64_t)k;
+        uint64_t lo = d_lo[k - 1], hi = n_docs;
+        while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (doc_off[mid] < target) lo = mid + 1; else hi = mid; }
+        d_lo[k] = lo;
+    }
+    d_lo[S] = n_docs;
+    // offsets relative to each piece's first byte
+    std::vector<uint64_t> rel((size_t)n_docs + (size_t)S + 1);
+    uint64_t rel0[9];
+    {
+        size_t w = 0;
+        for (int k = 0; k < S; k++) {
+            rel0[k] = w;
+            const uint64_t b0 = doc_off[d_lo[k]];
+            for (uint64_t d = d_lo[k]; d <= d_lo[k + 1]; d++) rel[w++] = doc_off[d] - b0;
+        }
+        rel0[S] = w;
+    }
+    HIPCHK(c, c->s_text.ensure(n_bytes + 16));
+    HIPCHK(c, c->s_off.ensure(rel.size() * 8));
+    for (int k = 0; k < S; k++) {
+        const uint64_t b0 = doc_off[d_lo[k]], b1 = doc_off[d_lo[k + 1]];
+        if (b1 > b0) HIPCHK(c, hipMemcpyAsync(c->s_text.as<uint8_t>() + b0, text + b0, b1 - b0, hipMemcpyHostToDevice, c->stream_in));
+        HIPCHK(c, hipMemcpyAsync(c->s_off.as<uint64_t>() + rel0[k], rel.data() + rel0[k], (rel0[k + 1] - rel0[k]) * 8,
+                                 hipMemcpyHostToDevice, c->stream_in));
+        HIPCHK(c, hipEventRecord(c->ev_in[k], c->stream_in));
+    }
+    uint64_t total = 0, base[9];
+    bool overflow = false;
+    uint64_t sum_counters[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < S; k++) {
+        const uint64_t nd = d_lo[k + 1] - d_lo[k];
+        const uint64_t b0 = doc_off[d_lo[k]], nb = doc_off[d_lo[k + 1]] - b0;
+        base[k] = total;
+        if (nd == 0) continue;
+        DevBuf& ob = c->p_out[k & 1];
+        DevBuf& oo = c->p_outoff[k & 1];
+        if (k >= 2) HIPCHK(c, hipEventSynchronize(c->ev_out[k & 1]));   // the download of piece k - 2 has left these buffers
+        HIPCHK(c, ob.ensure((nb / 3 + 2 * nd + 1024) * 4));
+        HIPCHK(c, oo.ensure((nd + 1) * 8));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[k], 0));
+        EncodeArgs A{};
+        A.text = c->s_text.as<uint8_t>() + b0; A.n_bytes = nb; A.doc_off = c->s_off.as<uint64_t>() + rel0[k]; A.n_docs = nd;
+        A.flags = flags; A.out_tok = ob.as<int32_t>(); A.out_cap = ob.cap / 4; A.out_off = oo.as<uint64_t>(); A.kinds = nullptr;
+        Workspace W{};
+        uint64_t tk = 0;
+        int rc = encode_core(c, A, c->stream, &tk, &W);
+        if (rc == L3_E_OUTPUT_CAP) {   // our guess was too small: enlarge and redo only the final scatter
+            HIPCHK(c, ob.ensure(tk * 4));
+            A.out_tok = ob.as<int32_t>();
+            A.out_cap = ob.cap / 4;
+            HIPCHK(c, launch_encode(c->T, W, A, c->stream, nullptr, true));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            rc = L3_OK;
+        }
+        if (rc) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamSynchronize(c->stream_out); return rc; }
+        for (int i = 0; i < 6; i++) sum_counters[i] += c->counters[i];
+        total += tk;
+        if (total > out_cap) overflow = true;
+        HIPCHK(c, hipMemcpyAsync(out_off + d_lo[k], oo.p, nd * 8, hipMemcpyDeviceToHost, c->stream_out));
+        if (!overflow && tk) HIPCHK(c, hipMemcpyAsync(out_tok + base[k], ob.p, tk * 4, hipMemcpyDeviceToHost, c->stream_out));
+        HIPCHK(c, hipEventRecord(c->ev_out[k & 1], c->stream_out));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream_in));
+    HIPCHK(c, hipStreamSynchronize(c->stream_out));
+    for (int k = 1; k < S; k++)
+        if (base[k]) for (uint64_t d = d_lo[k]; d < d_lo[k + 1]; d++) out_off[d] += base[k];
+    out_off[n_docs] = total;
+    for (int i = 0; i < 6; i++) c->counters[i] = sum_counters[i];
+    *n_tok = total;
+    if (overflow) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
+    return L3_OK;
+}
+
 int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                     int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok) {
     if (!c) return L3_E_INVALID_ARG;
@@ -349,6 +460,8 @@ int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uin
     const uint64_t n_bytes = doc_off[n_docs];
     if (!text && n_bytes) { c->err = "null text"; return L3_E_INVALID_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    if (n_bytes >= (16ull << 20) && n_docs >= 16 && is_pinned(text) && is_pinned(out_tok))   // (pageable copies do not overlap)
+        return encode_batch_pieces(c, text, doc_off, n_docs, flags, out_tok, out_cap, out_off, n_tok);
     hipStream_t s = c->stream;
     HIPCHK(c, c->s_text.ensure(n_bytes + 16));
     HIPCHK(c, c->s_off.ensure((n_docs + 1) * 8));

@@ -1983,7 +1983,10 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         L3_EV(kEvTile);
         {
             uint64_t mgrid = ((W.miss_shard_cap + kMergeThreads - 1) / kMergeThreads) * kMissShards;  // windows at most
-            if (mgrid > 2048) mgrid = 2048;
+#ifndef L3_MERGE_GRID
+#define L3_MERGE_GRID 2048
+#endif
+            if (mgrid > L3_MERGE_GRID) mgrid = L3_MERGE_GRID;
             if (mgrid == 0) mgrid = 1;
             hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)mgrid), dim3(kMergeThreads), 0, stream, T, W, A);
             L3_LAUNCH_CHECK();
