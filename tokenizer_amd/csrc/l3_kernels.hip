@@ -769,35 +769,38 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             bool probe[kLookU], again[kLookU];
 #pragma unroll
             for (int u = 0; u < kLookU; u++) {
+                // straight-line code on a clamped index (lanes past the end redo the last pre-token and are masked
+                // at the stores): the branches this replaces cost more scalar work than the lanes they saved
                 const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
-                probe[u] = false;
-                if (k < n_pre) {
-                    const int s = R.list[k];
-                    const int e = k + 1 < n_pre ? (int)R.list[k + 1] : last_e;
-                    const int len = e - s;
-                    const bool special = (R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull;
-                    const bool inval = any_inv && e >= 0 && any_bit_in(R.bm[B_INV], s, e);
-                    if (special || e < 0 || inval || len > kVocabInline) {
-                        const uint32_t idx = (uint32_t)atomicAdd(&vars[TV_NRARE], 1);
-                        if (idx < (uint32_t)kRareCap) R.rare[idx] = (uint16_t)k;
-                    } else {
-                        // little-endian words of the pre-token straight from the LDS image (unaligned start)
-                        const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
-                        const uint32_t sh = (uint32_t)(s & 3) * 8u;
-                        const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
-                        const uint32_t nw = ((uint32_t)len + 3u) >> 2;
-                        const uint32_t tail = (len & 3) ? (1u << ((len & 3) * 8)) - 1u : 0xFFFFFFFFu;
-                        uint32_t a0 = __funnelshift_r(x0, x1, sh), a1 = __funnelshift_r(x1, x2, sh), a2 = __funnelshift_r(x2, x3, sh);
-                        if (nw == 1) { a0 &= tail; a1 = 0; a2 = 0; }
-                        else if (nw == 2) { a1 &= tail; a2 = 0; }
-                        else a2 &= tail;
-                        w0[u] = a0; w1[u] = a1; w2[u] = a2; ln[u] = (uint32_t)len;
-                        uint32_t hb1;
-                        vocab_hash_short2(a0, a1, a2, (uint32_t)len, T.vocab_log2, &hb1, &hb2[u]);
-                        sl[u] = T.vocab_slots[hb1];
-                        probe[u] = true;
-                    }
+                const bool in = k < n_pre;
+                const uint32_t kk = in ? k : n_pre - 1u;
+                const int s = R.list[kk];
+                const int e_next = (int)R.list[kk + 1u < n_pre ? kk + 1u : kk];
+                const int e = kk + 1u < n_pre ? e_next : last_e;
+                const int len = e - s;
+                const bool special = (R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull;
+                const bool inval = any_inv && e >= 0 && any_bit_in(R.bm[B_INV], s, e);
+                const bool rare = special || e < 0 || inval || len > kVocabInline;
+                if (in && rare) {
+                    const uint32_t idx = (uint32_t)atomicAdd(&vars[TV_NRARE], 1);
+                    if (idx < (uint32_t)kRareCap) R.rare[idx] = (uint16_t)k;
                 }
+                // little-endian words of the pre-token straight from the LDS image (unaligned start), bytes past its
+                // length masked off: word j keeps min(max(len - 4j, 0), 4) bytes
+                const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
+                const uint32_t sh = (uint32_t)(s & 3) * 8u;
+                const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
+                const int l0 = len < 0 ? 0 : (len > 12 ? 12 : len);
+                const uint32_t t0 = (uint32_t)(l0 > 4 ? 4 : l0), t1 = (uint32_t)(l0 > 8 ? 4 : (l0 > 4 ? l0 - 4 : 0)),
+                               t2 = (uint32_t)(l0 > 8 ? l0 - 8 : 0);
+                const uint32_t a0 = __funnelshift_r(x0, x1, sh) & (uint32_t)((1ull << (8u * t0)) - 1ull);
+                const uint32_t a1 = __funnelshift_r(x1, x2, sh) & (uint32_t)((1ull << (8u * t1)) - 1ull);
+                const uint32_t a2 = __funnelshift_r(x2, x3, sh) & (uint32_t)((1ull << (8u * t2)) - 1ull);
+                w0[u] = a0; w1[u] = a1; w2[u] = a2; ln[u] = (uint32_t)l0;
+                uint32_t hb1;
+                vocab_hash_short2(a0, a1, a2, (uint32_t)l0, T.vocab_log2, &hb1, &hb2[u]);
+                sl[u] = T.vocab_slots[hb1];   // (in bounds whatever the lane holds)
+                probe[u] = in && !rare;
             }
 #pragma unroll
             for (int u = 0; u < kLookU; u++) {   // first choice missed: second bucket (tokens that lost their first choice, non-tokens)
