@@ -1248,56 +1248,78 @@ constexpr int32_t kDirtyBit = 1 << 29;
 // Returns the new n; sa/pa are left pointing at the buffers that hold the result.
 __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, int32_t*& sb, uint32_t*& pb, uint32_t n,
                                  uint32_t* tmp, unsigned long long* tmp64, Seg* segtmp) {
-    const uint32_t tid = threadIdx.x;
+    // Thread mapping: order-free sweeps go over i = tid, tid + 256, ...; the two sweeps that need the order (parity
+    // inside runs, compaction) give every wave one contiguous range, walked 64 symbols at a time with ballots.
+    // Either way the 64 lanes of a wave touch 64 consecutive words: coalesced in HBM, conflict-free in LDS.
+    const uint32_t tid = threadIdx.x, lane = (uint32_t)lane_id(), wave = (uint32_t)wave_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long best = ~0ull;  // smallest key of the coming round
+    for (uint32_t i = tid; i < n; i += kSlowThreads) {
+        const unsigned long long v = ((unsigned long long)pa[i] << 32) | i;
+        best = v < best ? v : best;
+    }
+    best = block_min64(best, tmp64);
     for (;;) {
         if (n < 2) break;
-        const uint32_t chunk = (n + kSlowThreads - 1) / kSlowThreads;
-        const uint32_t i0 = tid * chunk < n ? tid * chunk : n;
-        const uint32_t i1 = i0 + chunk < n ? i0 + chunk : n;
-        // (a) smallest key
-        unsigned long long best = ~0ull;
-        for (uint32_t i = i0; i < i1; i++) {
-            unsigned long long v = ((unsigned long long)pa[i] << 32) | i;
-            best = v < best ? v : best;
-        }
-        best = block_min64(best, tmp64);
         const uint32_t r = (uint32_t)(best >> 32);
         if (r == kNoPrio) break;
         const uint32_t ipos = (uint32_t)best;
         const bool same = (sa[ipos] & kIdMask) == (sa[ipos + 1] & kIdMask);
+        const uint32_t lw = ((n + kSlowThreads - 1) / kSlowThreads) * 64u;  // symbols per wave
+        const uint32_t w_lo = wave * lw < n ? wave * lw : n;
+        const uint32_t w_hi = w_lo + lw < n ? w_lo + lw : n;
         __syncthreads();
         // (b) the set S
         {
-            Seg sg; sg.cnt = 0; sg.open = 1;
-            uint32_t first_break = n;
-            for (uint32_t i = i0; i < i1; i++) {
-                const uint32_t p = pa[i];
-                int32_t v = sa[i] & kIdMask;
-                if (p != r) {
-                    sg.cnt = 0; sg.open = 0;
-                    if (first_break == n) first_break = i;
-                    if (p != kNoPrio) {  // strict local minimum of (rank, position); pa[n - 1] is kNoPrio
-                        const uint32_t pl = i >= 1 ? pa[i - 1] : kNoPrio, pn = pa[i + 1];
-                        if (pl > p && pn >= p) v |= kSelBit;
+            uint32_t carry = 0;  // same: length of the run of r that ends right before the current 64 symbols
+            if (same) {          // runs of r longer than one exist only when both symbols are equal
+                Seg sg; sg.cnt = 0; sg.open = 1;
+                for (uint32_t base = w_lo; base < w_hi; base += 64) {
+                    const uint32_t i = base + lane;
+                    const uint32_t vn = w_hi - base < 64u ? w_hi - base : 64u;
+                    const unsigned long long full = vn == 64u ? ~0ull : (1ull << vn) - 1ull;
+                    const unsigned long long m = __ballot(i < w_hi && pa[i] == r);
+                    if (m == full) {
+                        sg.cnt += vn;
+                    } else {
+                        const unsigned long long z = ~m & full;
+                        sg.cnt = vn - 1u - (63u - (uint32_t)__builtin_clzll(z));
+                        sg.open = 0;
                     }
-                } else {
-                    if (!(sg.cnt & 1u)) v |= kSelBit;
-                    sg.cnt++;
                 }
-                sa[i] = v;
+                if (lane == 0) segtmp[wave] = sg;
+                __syncthreads();
+                Seg c; c.cnt = 0; c.open = 1;
+                for (uint32_t w2 = 0; w2 < wave; w2++) c = seg_comb(c, segtmp[w2]);
+                carry = c.cnt;
             }
-            if (same) {  // runs of r can cross chunk borders only when both symbols are equal
-                Seg carry = block_seg_escan(sg, segtmp);
-                if (carry.cnt & 1u) {
-                    uint32_t lim = first_break < i1 ? first_break : i1;
-                    for (uint32_t i = i0; i < lim; i++) sa[i] ^= kSelBit;
+            for (uint32_t base = w_lo; base < w_hi; base += 64) {
+                const uint32_t i = base + lane;
+                const bool in = i < w_hi;
+                const uint32_t p = in ? pa[i] : kNoPrio;
+                const bool isr = in && p == r;
+                bool sel = isr;
+                if (same) {
+                    const unsigned long long m = __ballot(isr);
+                    const unsigned long long z = ~m & lt;
+                    const uint32_t idx = z ? lane - (63u - (uint32_t)__builtin_clzll(z)) - 1u : lane + carry;
+                    sel = isr && !(idx & 1u);
+                    const unsigned long long zz = ~m;
+                    carry = zz ? (uint32_t)__builtin_clzll(zz) : carry + 64u;
+                }
+                if (in) {
+                    if (!isr && p != kNoPrio) {  // strict local minimum of (rank, position); pa[n - 1] is kNoPrio
+                        const uint32_t pl = i >= 1 ? pa[i - 1] : kNoPrio, pn = pa[i + 1];
+                        sel = pl > p && pn >= p;
+                    }
+                    sa[i] = (sa[i] & kIdMask) | (sel ? kSelBit : 0);
                 }
             }
         }
         __syncthreads();
         // (c) theta
         unsigned long long th = ~0ull;
-        for (uint32_t i = i0; i < i1; i++) {
+        for (uint32_t i = tid; i < n; i += kSlowThreads) {
             const uint32_t p = pa[i];
             if (p == kNoPrio) continue;
             const unsigned long long key = ((unsigned long long)p << 32) | i;
@@ -1307,53 +1329,73 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
                 continue;
             }
             const uint32_t m = prio_merged_id(p);
-            uint32_t v = kNoPrio;
-            if (i >= 1) {
-                uint32_t lsym = (uint32_t)(sa[i - 1] & kIdMask);
+            const bool hasl = i >= 1, hasr = i + 2 < n;
+            uint32_t lsym = 0, rsym = 0;
+            if (hasl) {
+                lsym = (uint32_t)(sa[i - 1] & kIdMask);
                 if (i >= 2 && (sa[i - 2] & kSelBit) && pa[i - 2] <= p) lsym = prio_merged_id(pa[i - 2]);
-                v = pair_prio(T, lsym, m);
             }
-            if (i + 2 < n) {
-                uint32_t rsym = (uint32_t)(sa[i + 2] & kIdMask);
+            if (hasr) {
+                rsym = (uint32_t)(sa[i + 2] & kIdMask);
                 if ((sa[i + 2] & kSelBit) && pa[i + 2] < p) rsym = prio_merged_id(pa[i + 2]);
-                const uint32_t v2 = pair_prio(T, m, rsym);
-                v = v2 < v ? v2 : v;
             }
+            uint32_t v1, v2;
+            pair_prio2(T, lsym, m, m, rsym, &v1, &v2);  // both probes in flight together
+            if (!hasl) v1 = kNoPrio;
+            if (!hasr) v2 = kNoPrio;
+            const uint32_t v = v2 < v1 ? v2 : v1;
             unsigned long long beta = v == kNoPrio ? ~0ull : ((unsigned long long)v << 32);
             if (beta < key + 1) beta = key + 1;
             th = beta < th ? beta : th;
         }
         th = block_min64(th, tmp64);
         // (d) apply the members of S below theta, compacting into the other buffer
-        uint32_t live = 0;
-        for (uint32_t i = i0; i < i1; i++) {
-            const bool dead = i >= 1 && (sa[i - 1] & kSelBit) && (((unsigned long long)pa[i - 1] << 32) | (i - 1)) < th;
-            live += dead ? 0u : 1u;
+        uint32_t cnt = 0;
+        for (uint32_t base = w_lo; base < w_hi; base += 64) {
+            const uint32_t i = base + lane;
+            const bool in = i < w_hi;
+            const bool dead = in && i >= 1 && (sa[i - 1] & kSelBit) && (((unsigned long long)pa[i - 1] << 32) | (i - 1)) < th;
+            cnt += (uint32_t)__popcll(__ballot(in && !dead));
         }
-        uint32_t n2;
-        uint32_t j = block_escan(live, tmp, &n2);
-        for (uint32_t i = i0; i < i1; i++) {
-            const bool dead = i >= 1 && (sa[i - 1] & kSelBit) && (((unsigned long long)pa[i - 1] << 32) | (i - 1)) < th;
-            if (dead) continue;
-            const bool applied = (sa[i] & kSelBit) && (((unsigned long long)pa[i] << 32) | i) < th;
-            sb[j] = applied ? (int32_t)(prio_merged_id(pa[i]) | (uint32_t)kDirtyBit) : (sa[i] & kIdMask);
-            pb[j] = pa[i];
-            j++;
-        }
+        if (lane == 0) tmp[wave] = cnt;
         __syncthreads();
-        // (e) re-probe the pairs that touch a merged symbol
-        {
-            const uint32_t chunk2 = (n2 + kSlowThreads - 1) / kSlowThreads;
-            const uint32_t j0 = tid * chunk2 < n2 ? tid * chunk2 : n2;
-            const uint32_t j1 = j0 + chunk2 < n2 ? j0 + chunk2 : n2;
-            for (uint32_t q = j0; q < j1; q++) {
-                int32_t x = sb[q];
-                int32_t y = q + 1 < n2 ? sb[q + 1] : 0;
-                if (!((x | y) & kDirtyBit)) continue;
-                pb[q] = q + 1 < n2 ? pair_prio(T, (uint32_t)(x & kIdMask), (uint32_t)(y & kIdMask)) : kNoPrio;
+        uint32_t j0 = 0, n2 = 0;
+        for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+            const uint32_t x = tmp[w2];
+            if (w2 < wave) j0 += x;
+            n2 += x;
+        }
+        for (uint32_t base = w_lo; base < w_hi; base += 64) {
+            const uint32_t i = base + lane;
+            const bool in = i < w_hi;
+            const bool dead = in && i >= 1 && (sa[i - 1] & kSelBit) && (((unsigned long long)pa[i - 1] << 32) | (i - 1)) < th;
+            const bool live = in && !dead;
+            const unsigned long long lm = __ballot(live);
+            if (live) {
+                const uint32_t j = j0 + (uint32_t)__popcll(lm & lt);
+                const uint32_t p = pa[i];
+                const int32_t x = sa[i];
+                const bool applied = (x & kSelBit) && (((unsigned long long)p << 32) | i) < th;
+                sb[j] = applied ? (int32_t)(prio_merged_id(p) | (uint32_t)kDirtyBit) : (x & kIdMask);
+                pb[j] = p;
             }
+            j0 += (uint32_t)__popcll(lm);
         }
         __syncthreads();
+        // (e) re-probe the pairs that touch a merged symbol; the smallest key of the next round on the way
+        best = ~0ull;
+        for (uint32_t q = tid; q < n2; q += kSlowThreads) {
+            const int32_t x = sb[q];
+            const int32_t y = q + 1 < n2 ? sb[q + 1] : 0;
+            uint32_t p = pb[q];
+            if ((x | y) & kDirtyBit) {
+                p = q + 1 < n2 ? pair_prio(T, (uint32_t)(x & kIdMask), (uint32_t)(y & kIdMask)) : kNoPrio;
+                pb[q] = p;
+            }
+            const unsigned long long v = ((unsigned long long)p << 32) | q;
+            best = v < best ? v : best;
+        }
+        best = block_min64(best, tmp64);
         { int32_t* t = sa; sa = sb; sb = t; }
         { uint32_t* t = pa; pa = pb; pb = t; }
         n = n2;
@@ -1428,14 +1470,28 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
         }
         // ---- 2. symbols: one per byte, EF BF BD for a byte that is not valid UTF-8 (state_machine.go:36)
         GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
-        const uint64_t bchunk = (len + kSlowThreads - 1) / kSlowThreads;
-        const uint64_t b0 = tid * bchunk < len ? tid * bchunk : len;
-        const uint64_t b1 = b0 + bchunk < len ? b0 + bchunk : len;
+        // every wave takes one contiguous range of the bytes, 64 at a time (coalesced reads, order by ballots)
+        const uint32_t lane = (uint32_t)lane_id(), wave = (uint32_t)wave_id();
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint64_t bw = ((len + kSlowThreads - 1) / kSlowThreads) * 64u;
+        const uint64_t b0 = wave * bw < len ? wave * bw : len;
+        const uint64_t b1 = b0 + bw < len ? b0 + bw : len;
         uint32_t nsym = 0;
-        for (uint64_t q = b0; q < b1; q++)
-            nsym += (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID) ? 3u : 1u;
-        uint32_t L;
-        uint32_t so = block_escan(nsym, tmp, &L);
+        for (uint64_t base = b0; base < b1; base += 64) {
+            const uint64_t q = base + lane;
+            const bool in = q < b1;
+            const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
+            nsym += (uint32_t)__popcll(__ballot(in)) + 2u * (uint32_t)__popcll(__ballot(inv));
+        }
+        if (lane == 0) tmp[wave] = nsym;
+        __syncthreads();
+        uint32_t L = 0, so = 0;
+        for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+            const uint32_t x = tmp[w2];
+            if (w2 < wave) so += x;
+            L += x;
+        }
+        __syncthreads();
         int32_t *sa, *sb;
         uint32_t *pa, *pb;
         bool ok = true;
@@ -1461,12 +1517,18 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
         if (ok) {
             // symbol bytes first, then pair priorities, then ids
             uint32_t o = so;
-            for (uint64_t q = b0; q < b1; q++) {
-                if (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID) {
-                    sa[o++] = 0xEF; sa[o++] = 0xBF; sa[o++] = 0xBD;
-                } else {
-                    sa[o++] = A.text[start + q];
+            for (uint64_t base = b0; base < b1; base += 64) {
+                const uint64_t q = base + lane;
+                const bool in = q < b1;
+                const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
+                const unsigned long long mi = __ballot(in), mv = __ballot(inv);
+                const uint32_t pos = o + (uint32_t)__popcll(mi & lt) + 2u * (uint32_t)__popcll(mv & lt);
+                if (inv) {
+                    sa[pos] = 0xEF; sa[pos + 1] = 0xBF; sa[pos + 2] = 0xBD;
+                } else if (in) {
+                    sa[pos] = A.text[start + q];
                 }
+                o += (uint32_t)__popcll(mi) + 2u * (uint32_t)__popcll(mv);
             }
             __syncthreads();
             int32_t whole = -1;
@@ -1482,13 +1544,10 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
                 n_out = 1;
                 __syncthreads();
             } else {
-                const uint32_t chunk = (L + kSlowThreads - 1) / kSlowThreads;
-                const uint32_t i0 = (uint32_t)tid * chunk < L ? tid * chunk : L;
-                const uint32_t i1 = i0 + chunk < L ? i0 + chunk : L;
-                for (uint32_t i = i0; i < i1; i++)
+                for (uint32_t i = (uint32_t)tid; i < L; i += kSlowThreads)
                     pa[i] = i + 1 < L ? T.bytepair[((uint32_t)sa[i] << 8) | (uint32_t)sa[i + 1]] : kNoPrio;
                 __syncthreads();
-                for (uint32_t i = i0; i < i1; i++) sa[i] = T.byte_tok[sa[i]];
+                for (uint32_t i = (uint32_t)tid; i < L; i += kSlowThreads) sa[i] = T.byte_tok[sa[i]];
                 __syncthreads();
                 n_out = merge_rounds(T, sa, pa, sb, pb, L, tmp, tmp64, segtmp);
             }
