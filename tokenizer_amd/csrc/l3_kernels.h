@@ -22,7 +22,10 @@ constexpr int kLaneMax = 64;      // longest pre-token (bytes) merged by a singl
 constexpr int kTileCap = kTile;  // stream items one tile can emit: one per pre-token that starts in it
 constexpr int kTileThreads = 256;
 constexpr int kSlowThreads = 256;
-constexpr int kSlowLds = 3072;    // symbols of a slow pre-token merged in LDS; longer ones use HBM scratch
+#ifndef L3_SLOW_LDS
+#define L3_SLOW_LDS 3072
+#endif
+constexpr int kSlowLds = L3_SLOW_LDS;    // symbols of a slow pre-token merged in LDS; longer ones use HBM scratch
 
 // A stream item is a token id (>= 0) or the placeholder -2 - e of a deferred pre-token: e < kSlowBase
 // is an index into Workspace::miss_in / miss_res (short: merged one lane each by merge_kernel), e >= kSlowBase is
@@ -56,7 +59,7 @@ struct Status {
     uint32_t slow_count;        // entries appended so far (may exceed capacity: overflow)
     uint32_t flags;             // kOvf* / kBadOffsets
     uint32_t generic_tiles;     // tiles the fast emit kernel left to the generic one (the host launches it only then)
-    uint32_t pad1;
+    uint32_t slow_next;         // next entry of the slow list to hand out (work queue of slow_kernel)
     unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
     unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the scan)
     unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)

@@ -1416,11 +1416,18 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
     const int tid = threadIdx.x;
     uint64_t n_slow = W.status->slow_count;
     if (n_slow > W.slow_cap) n_slow = W.slow_cap;
+    // The entries differ in length by three orders of magnitude, so they are handed out one at a time from a counter
+    // (a fixed split left the workgroup with the longest entries running long after the others).  Every workgroup
+    // leaves at the first index past the end.
 #pragma unroll 1
-    for (uint64_t ei = blockIdx.x; ei < n_slow; ei += gridDim.x) {
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) ivars[1] = (int)atomicAdd(&W.status->slow_next, 1u);
+        __syncthreads();
+        const uint64_t ei = (uint32_t)ivars[1];
+        if (ei >= n_slow) break;
         const uint64_t start = W.slow[ei].start;
         uint64_t len = W.slow[ei].len;
-        __syncthreads();
         // ---- 1. where does it end? (state_machine.go:53-79 continues until the next matcher start)
         if (len == 0) {
             RegionLds& R = S.R;
