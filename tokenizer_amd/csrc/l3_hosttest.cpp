@@ -2,6 +2,8 @@
 // table builder, exported for the CPU test-suite (tests/test_rules_host.py).  It lets the position-local
 // pre-tokenizer rules, the table probes and the merge loop be fuzzed against the oracle without a
 // GPU.  It is a unit-test shim: nothing in the product calls it and it is not a CPU fallback.
+#include <cstdio>
+#include <cstdlib>
 #include <stdlib.h>
 #include <string.h>
 
@@ -235,6 +237,11 @@ int64_t l3t_bpe_rounds(void* hp, const uint8_t* bytes, int64_t n0, int32_t* out,
             bool d = dirty[q] || (q + 1 < n2 && dirty[q + 1]);
             if (!d) continue;
             pb[q] = q + 1 < n2 ? pair_prio(T, (uint32_t)sb[q], (uint32_t)sb[q + 1]) : kNoPrio;
+        }
+        if (getenv("L3T_TRACE")) {
+            size_t cand = 0;
+            for (size_t q = 0; q < n2; q++) cand += pb[q] != kNoPrio;
+            fprintf(stderr, "round %lld: n %zu -> %zu, candidates left %zu\n", (long long)nr, n, n2, cand);
         }
         sa.swap(sb); pa.swap(pb);
         n = n2;

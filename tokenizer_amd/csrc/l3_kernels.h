@@ -23,9 +23,14 @@ constexpr int kTileCap = kTile;  // stream items one tile can emit: one per pre-
 constexpr int kTileThreads = 256;
 constexpr int kSlowThreads = 256;
 #ifndef L3_SLOW_LDS
-#define L3_SLOW_LDS 3072
+#define L3_SLOW_LDS 2048
 #endif
 constexpr int kSlowLds = L3_SLOW_LDS;    // symbols of a slow pre-token merged in LDS; longer ones use HBM scratch
+#ifndef L3_MID_BYTES
+#define L3_MID_BYTES 512
+#endif
+constexpr int kMidBytes = L3_MID_BYTES;  // slow entries of known length up to this are merged by ONE wave each
+constexpr int kMidSyms = L3_SLOW_LDS / 4; // ... in LDS when they have at most this many symbols (four waves share the arena)
 
 // A stream item is a token id (>= 0) or the placeholder -2 - e of a deferred pre-token: e < kSlowBase
 // is an index into Workspace::miss_in / miss_res (short: merged one lane each by merge_kernel), e >= kSlowBase is
@@ -42,7 +47,7 @@ struct SlowEntry {
     uint32_t len;        // source bytes, 0 = unknown (ends beyond the tile's look-ahead)
     uint32_t tile;       // owning tile
     uint32_t count;      // tokens produced (written by the slow kernel)
-    uint32_t pad;
+    uint32_t pad;        // written by mid_kernel: see Status::slow_q
     uint64_t pool_off;   // first token in the slow pool (written by the slow kernel)
 };
 
@@ -59,7 +64,7 @@ struct Status {
     uint32_t slow_count;        // entries appended so far (may exceed capacity: overflow)
     uint32_t flags;             // kOvf* / kBadOffsets
     uint32_t generic_tiles;     // tiles the fast emit kernel left to the generic one (the host launches it only then)
-    uint32_t slow_next;         // next entry of the slow list to hand out (work queue of slow_kernel)
+    uint32_t pad1;
     unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
     unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the scan)
     unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)
@@ -70,6 +75,11 @@ struct Status {
         uint32_t pad;
         unsigned long long pool_used;   // tokens reserved in the shard's part of the pool (may exceed mpool_shard_cap)
     } shard[64];
+    // Work queues over the slow list, on cache lines of their own.  mid_q: mid_kernel's waves take the list a few
+    // entries at a time, do the entries of known, moderate length themselves and note the others in SlowEntry::pad
+    // (pad of entry k = index of the k-th such entry, slow_q.count of them); slow_q: slow_kernel's workgroups take
+    // those one at a time.
+    struct alignas(128) Queue { uint32_t next, count; } slow_q, mid_q;
 };
 constexpr int kMissShards = 64;
 // a short deferred pre-token (input of merge_kernel).  Its result is one word of miss_res: bits 0..7 = n tokens;

@@ -1223,6 +1223,10 @@ struct MergeLds {
     int32_t sA[kSlowLds], sB[kSlowLds];
     uint32_t pA[kSlowLds], pB[kSlowLds];
 };
+struct MidLds {  // one wave's share of the arena
+    int32_t sA[kMidSyms], sB[kMidSyms];
+    uint32_t pA[kMidSyms], pB[kMidSyms];
+};
 union SlowLds {
     RegionLds R;
     MergeLds M;
@@ -1246,29 +1250,56 @@ constexpr int32_t kDirtyBit = 1 << 29;
 // steps of the sequential algorithm (everything with a smaller key is applied, dead, or a new pair with
 // key >= theta), so the result is identical.  The pair with the smallest key always qualifies.
 // Returns the new n; sa/pa are left pointing at the buffers that hold the result.
+// WAVE = false: the whole workgroup works on one pre-token; WAVE = true: the calling wave alone does (no workgroup
+// barrier anywhere on that path; tmp / tmp64 / segtmp unused).
+template <bool WAVE>
+__device__ __forceinline__ void group_sync() {
+    if (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the wave's LDS / memory operations complete in order
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+template <bool WAVE>
+__device__ __forceinline__ unsigned long long group_min64(unsigned long long v, unsigned long long* tmp64) {
+    if (WAVE) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            unsigned long long o = __shfl_xor(v, d, 64);
+            v = o < v ? o : v;
+        }
+        return v;
+    } else {
+        return block_min64(v, tmp64);
+    }
+}
+template <bool WAVE>
 __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, int32_t*& sb, uint32_t*& pb, uint32_t n,
                                  uint32_t* tmp, unsigned long long* tmp64, Seg* segtmp) {
     // Thread mapping: order-free sweeps go over i = tid, tid + 256, ...; the two sweeps that need the order (parity
     // inside runs, compaction) give every wave one contiguous range, walked 64 symbols at a time with ballots.
     // Either way the 64 lanes of a wave touch 64 consecutive words: coalesced in HBM, conflict-free in LDS.
-    const uint32_t tid = threadIdx.x, lane = (uint32_t)lane_id(), wave = (uint32_t)wave_id();
+    constexpr uint32_t kGroup = WAVE ? 64u : (uint32_t)kSlowThreads;
+    const uint32_t lane = (uint32_t)lane_id(), wave = WAVE ? 0u : (uint32_t)wave_id();
+    const uint32_t tid = WAVE ? lane : threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned long long best = ~0ull;  // smallest key of the coming round
-    for (uint32_t i = tid; i < n; i += kSlowThreads) {
+    for (uint32_t i = tid; i < n; i += kGroup) {
         const unsigned long long v = ((unsigned long long)pa[i] << 32) | i;
         best = v < best ? v : best;
     }
-    best = block_min64(best, tmp64);
+    best = group_min64<WAVE>(best, tmp64);
     for (;;) {
         if (n < 2) break;
         const uint32_t r = (uint32_t)(best >> 32);
         if (r == kNoPrio) break;
         const uint32_t ipos = (uint32_t)best;
         const bool same = (sa[ipos] & kIdMask) == (sa[ipos + 1] & kIdMask);
-        const uint32_t lw = ((n + kSlowThreads - 1) / kSlowThreads) * 64u;  // symbols per wave
+        const uint32_t lw = ((n + kGroup - 1) / kGroup) * 64u;  // symbols per wave
         const uint32_t w_lo = wave * lw < n ? wave * lw : n;
         const uint32_t w_hi = w_lo + lw < n ? w_lo + lw : n;
-        __syncthreads();
+        group_sync<WAVE>();
         // (b) the set S
         {
             uint32_t carry = 0;  // same: length of the run of r that ends right before the current 64 symbols
@@ -1287,11 +1318,13 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
                         sg.open = 0;
                     }
                 }
-                if (lane == 0) segtmp[wave] = sg;
-                __syncthreads();
-                Seg c; c.cnt = 0; c.open = 1;
-                for (uint32_t w2 = 0; w2 < wave; w2++) c = seg_comb(c, segtmp[w2]);
-                carry = c.cnt;
+                if (!WAVE) {
+                    if (lane == 0) segtmp[wave] = sg;
+                    __syncthreads();
+                    Seg c; c.cnt = 0; c.open = 1;
+                    for (uint32_t w2 = 0; w2 < wave; w2++) c = seg_comb(c, segtmp[w2]);
+                    carry = c.cnt;
+                }
             }
             for (uint32_t base = w_lo; base < w_hi; base += 64) {
                 const uint32_t i = base + lane;
@@ -1316,10 +1349,10 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
                 }
             }
         }
-        __syncthreads();
+        group_sync<WAVE>();
         // (c) theta
         unsigned long long th = ~0ull;
-        for (uint32_t i = tid; i < n; i += kSlowThreads) {
+        for (uint32_t i = tid; i < n; i += kGroup) {
             const uint32_t p = pa[i];
             if (p == kNoPrio) continue;
             const unsigned long long key = ((unsigned long long)p << 32) | i;
@@ -1348,7 +1381,7 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
             if (beta < key + 1) beta = key + 1;
             th = beta < th ? beta : th;
         }
-        th = block_min64(th, tmp64);
+        th = group_min64<WAVE>(th, tmp64);
         // (d) apply the members of S below theta, compacting into the other buffer
         uint32_t cnt = 0;
         for (uint32_t base = w_lo; base < w_hi; base += 64) {
@@ -1357,13 +1390,16 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
             const bool dead = in && i >= 1 && (sa[i - 1] & kSelBit) && (((unsigned long long)pa[i - 1] << 32) | (i - 1)) < th;
             cnt += (uint32_t)__popcll(__ballot(in && !dead));
         }
-        if (lane == 0) tmp[wave] = cnt;
-        __syncthreads();
-        uint32_t j0 = 0, n2 = 0;
-        for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
-            const uint32_t x = tmp[w2];
-            if (w2 < wave) j0 += x;
-            n2 += x;
+        uint32_t j0 = 0, n2 = cnt;
+        if (!WAVE) {
+            if (lane == 0) tmp[wave] = cnt;
+            __syncthreads();
+            n2 = 0;
+            for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+                const uint32_t x = tmp[w2];
+                if (w2 < wave) j0 += x;
+                n2 += x;
+            }
         }
         for (uint32_t base = w_lo; base < w_hi; base += 64) {
             const uint32_t i = base + lane;
@@ -1381,10 +1417,10 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
             }
             j0 += (uint32_t)__popcll(lm);
         }
-        __syncthreads();
+        group_sync<WAVE>();
         // (e) re-probe the pairs that touch a merged symbol; the smallest key of the next round on the way
         best = ~0ull;
-        for (uint32_t q = tid; q < n2; q += kSlowThreads) {
+        for (uint32_t q = tid; q < n2; q += kGroup) {
             const int32_t x = sb[q];
             const int32_t y = q + 1 < n2 ? sb[q + 1] : 0;
             uint32_t p = pb[q];
@@ -1395,12 +1431,160 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
             const unsigned long long v = ((unsigned long long)p << 32) | q;
             best = v < best ? v : best;
         }
-        best = block_min64(best, tmp64);
+        best = group_min64<WAVE>(best, tmp64);
         { int32_t* t = sa; sa = sb; sb = t; }
         { uint32_t* t = pa; pa = pb; pb = t; }
         n = n2;
     }
     return n;
+}
+
+// One slow entry of known, moderate length (<= kMidBytes source bytes), handled by the calling wave alone: a
+// workgroup per entry spends most of its time in barriers and probe round trips at these sizes, four independent
+// waves keep four entries in flight instead.  Same steps as the workgroup path below, wave-wide.
+// symbols of the entry: one per byte, three (EF BF BD) for a byte that is not valid UTF-8 (state_machine.go:36)
+__device__ __forceinline__ uint32_t mid_symbols(const Tables& T, const EncodeArgs& A, uint64_t start, uint32_t len) {
+    const uint32_t lane = (uint32_t)lane_id();
+    GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
+    uint32_t L = 0;
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t q = base + lane;
+        const bool in = q < len;
+        const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
+        L += (uint32_t)__popcll(__ballot(in)) + 2u * (uint32_t)__popcll(__ballot(inv));
+    }
+    return L;
+}
+// The entry's tokens, by the calling wave alone; L = mid_symbols(); poff = where its tokens go in the slow pool
+// (room for L of them), -1: no room.
+__device__ void mid_entry(const Tables& T, const Workspace& W, const EncodeArgs& A, uint64_t ei, uint32_t L, long long poff,
+                          MidLds& M) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint64_t start = W.slow[ei].start;
+    const uint32_t len = W.slow[ei].len;
+    GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
+    group_sync<true>();  // the arena may still be read by this wave's previous entry
+    int32_t *sa = M.sA, *sb = M.sB;
+    uint32_t *pa = M.pA, *pb = M.pB;
+    if (L > (uint32_t)kMidSyms) {  // many invalid bytes: the arrays go to the HBM scratch
+        long long off = 0;
+        if (lane == 0) {
+            const unsigned long long need = (unsigned long long)L * 16ull;
+            const unsigned long long o = atomicAdd(&W.status->scratch_used, need);
+            off = (o + need <= W.scratch_cap) ? (long long)o : -1ll;
+            if (off < 0) atomicOr(&W.status->flags, kOvfScratch);
+        }
+        off = __shfl(off, 0, 64);
+        if (off < 0) return;
+        uint8_t* base = W.scratch + off;
+        sa = reinterpret_cast<int32_t*>(base);
+        sb = sa + L;
+        pa = reinterpret_cast<uint32_t*>(sb + L);
+        pb = pa + L;
+    }
+    uint32_t o = 0;
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t q = base + lane;
+        const bool in = q < len;
+        const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
+        const unsigned long long mi = __ballot(in), mv = __ballot(inv);
+        const uint32_t pos = o + (uint32_t)__popcll(mi & lt) + 2u * (uint32_t)__popcll(mv & lt);
+        if (inv) {
+            sa[pos] = 0xEF; sa[pos + 1] = 0xBF; sa[pos + 2] = 0xBD;
+        } else if (in) {
+            sa[pos] = A.text[start + q];
+        }
+        o += (uint32_t)__popcll(mi) + 2u * (uint32_t)__popcll(mv);
+    }
+    group_sync<true>();
+    int32_t whole = -1;
+    if (L <= (uint32_t)kMaxTokenBytes) {  // bpe.go:27-33
+        if (lane == 0) whole = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)sa[i]; }, L);
+        whole = __shfl(whole, 0, 64);
+    }
+    uint32_t n_out;
+    if (whole >= 0) {
+        if (lane == 0) sa[0] = whole;
+        n_out = 1;
+        group_sync<true>();
+    } else {
+        for (uint32_t i = lane; i < L; i += 64)
+            pa[i] = i + 1 < L ? T.bytepair[((uint32_t)sa[i] << 8) | (uint32_t)sa[i + 1]] : kNoPrio;
+        group_sync<true>();
+        for (uint32_t i = lane; i < L; i += 64) sa[i] = T.byte_tok[sa[i]];
+        group_sync<true>();
+        n_out = merge_rounds<true>(T, sa, pa, sb, pb, L, nullptr, nullptr, nullptr);
+        group_sync<true>();
+    }
+    if (poff < 0) return;
+    if (lane == 0) {
+        W.slow[ei].count = n_out;
+        W.slow[ei].pool_off = (unsigned long long)kMissShards * W.mpool_shard_cap + (unsigned long long)poff;
+        if (n_out > 1) atomicAdd(&W.tile_extra[W.slow[ei].tile], n_out - 1);
+    }
+    int32_t* dst = W.pool + (unsigned long long)kMissShards * W.mpool_shard_cap + poff;
+    for (uint32_t i = lane; i < n_out; i += 64) dst[i] = sa[i] & kIdMask;
+}
+
+// Every wave on its own takes a few entries of the slow list at a time, handles those of known, moderate length and
+// notes the others for slow_kernel (Status::slow_q).  Room in the slow pool is reserved once per visit, one token
+// per symbol of the entries taken (a returning atomic per entry on the one counter queued up: 0.3 ms for 58 k entries).
+constexpr int kMidPop = 8;
+__global__ __launch_bounds__(kSlowThreads) void mid_kernel(Tables T, Workspace W, EncodeArgs A) {
+    __shared__ __align__(16) MidLds mid[kSlowThreads / 64];
+    if (W.status->flags & kBadOffsets) return;
+    uint64_t n_slow = W.status->slow_count;
+    if (n_slow > W.slow_cap) n_slow = W.slow_cap;
+    const uint32_t lane = (uint32_t)lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    MidLds& M = mid[wave_id()];
+    // entries per visit to the counter: few enough that every wave of the grid gets some, at most kMidPop
+    uint32_t pop = (uint32_t)(n_slow / ((uint64_t)gridDim.x * (kSlowThreads / 64)));
+    pop = pop < 1u ? 1u : pop > (uint32_t)kMidPop ? (uint32_t)kMidPop : pop;
+#pragma unroll 1
+    for (;;) {
+        uint32_t e0 = 0;
+        if (lane == 0) e0 = atomicAdd(&W.status->mid_q.next, pop);
+        e0 = __shfl(e0, 0, 64);
+        if (e0 >= n_slow) break;
+        const uint32_t e = e0 + lane;
+        const bool in = lane < pop && e < n_slow;
+        const uint32_t len = in ? W.slow[e].len : 1u;
+        const uint64_t start = in ? W.slow[e].start : 0ull;
+        const bool big = in && (len == 0 || len > (uint32_t)kMidBytes);
+        const unsigned long long bm = __ballot(big);
+        if (bm) {  // not for a single wave: noted for slow_kernel
+            uint32_t k0 = 0;
+            if (lane == 0) k0 = atomicAdd(&W.status->slow_q.count, (uint32_t)__popcll(bm));
+            k0 = __shfl(k0, 0, 64);
+            if (big) W.slow[k0 + (uint32_t)__popcll(bm & lt)].pad = e;
+        }
+        const unsigned long long mm = __ballot(in && !big);
+        if (!mm) continue;
+        uint32_t my_l = 0;  // lane b: symbols of entry e0 + b
+        for (unsigned long long m = mm; m; m &= m - 1ull) {
+            const int b = __builtin_ctzll(m);
+            const uint32_t lb = mid_symbols(T, A, __shfl(start, b, 64), __shfl(len, b, 64));
+            if (lane == (uint32_t)b) my_l = lb;
+        }
+        const uint32_t inc = wave_iscan(my_l);
+        const uint32_t total = __shfl(inc, 63, 64);
+        long long base = 0;
+        if (lane == 0) {
+            const unsigned long long off = atomicAdd(&W.status->pool_used, (unsigned long long)total);
+            const bool fits = off + total <= W.pool_cap;
+            if (!fits) atomicOr(&W.status->flags, kOvfPool);
+            base = fits ? (long long)off : -1ll;
+        }
+        base = __shfl(base, 0, 64);
+        for (unsigned long long m = mm; m; m &= m - 1ull) {
+            const int b = __builtin_ctzll(m);
+            const uint32_t lb = __shfl(my_l, b, 64);
+            const uint32_t pre = __shfl(inc, b, 64) - lb;
+            mid_entry(T, W, A, e0 + (uint32_t)b, lb, base < 0 ? -1ll : base + (long long)pre, M);
+        }
+    }
 }
 
 __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace W, EncodeArgs A) {
@@ -1414,18 +1598,18 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
 
     if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x;
-    uint64_t n_slow = W.status->slow_count;
-    if (n_slow > W.slow_cap) n_slow = W.slow_cap;
+    const uint32_t n_big = W.status->slow_q.count;  // final: mid_kernel has run
+    // Entries of known, moderate length were mid_kernel's; the rest, a workgroup per entry:
     // The entries differ in length by three orders of magnitude, so they are handed out one at a time from a counter
     // (a fixed split left the workgroup with the longest entries running long after the others).  Every workgroup
     // leaves at the first index past the end.
 #pragma unroll 1
     for (;;) {
         __syncthreads();
-        if (tid == 0) ivars[1] = (int)atomicAdd(&W.status->slow_next, 1u);
+        if (tid == 0) ivars[1] = (int)atomicAdd(&W.status->slow_q.next, 1u);
         __syncthreads();
-        const uint64_t ei = (uint32_t)ivars[1];
-        if (ei >= n_slow) break;
+        if ((uint32_t)ivars[1] >= n_big) break;
+        const uint64_t ei = W.slow[(uint32_t)ivars[1]].pad;
         const uint64_t start = W.slow[ei].start;
         uint64_t len = W.slow[ei].len;
         // ---- 1. where does it end? (state_machine.go:53-79 continues until the next matcher start)
@@ -1556,7 +1740,7 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
                 __syncthreads();
                 for (uint32_t i = (uint32_t)tid; i < L; i += kSlowThreads) sa[i] = T.byte_tok[sa[i]];
                 __syncthreads();
-                n_out = merge_rounds(T, sa, pa, sb, pb, L, tmp, tmp64, segtmp);
+                n_out = merge_rounds<false>(T, sa, pa, sb, pb, L, tmp, tmp64, segtmp);
             }
             // ---- 3. tokens to the pool
             if (tid == 0) {
@@ -2063,6 +2247,8 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         L3_EV(kEvMerge);
         uint64_t sgrid = W.slow_cap < 2048 ? W.slow_cap : 2048;
         if (sgrid == 0) sgrid = 1;
+        hipLaunchKernelGGL(mid_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A);
+        L3_LAUNCH_CHECK();
         hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A);
         L3_LAUNCH_CHECK();
         L3_EV(kEvSlow);
