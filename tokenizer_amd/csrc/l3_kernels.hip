@@ -1542,11 +1542,17 @@ __global__ __launch_bounds__(kSlowThreads) void mid_kernel(Tables T, Workspace W
     // entries per visit to the counter: few enough that every wave of the grid gets some, at most kMidPop
     uint32_t pop = (uint32_t)(n_slow / ((uint64_t)gridDim.x * (kSlowThreads / 64)));
     pop = pop < 1u ? 1u : pop > (uint32_t)kMidPop ? (uint32_t)kMidPop : pop;
+    // the first visit needs no counter: wave g starts at g * pop (an empty or short list costs no atomics at all)
+    const uint32_t n_waves = gridDim.x * (uint32_t)(kSlowThreads / 64);
+    bool first = true;
 #pragma unroll 1
     for (;;) {
-        uint32_t e0 = 0;
-        if (lane == 0) e0 = atomicAdd(&W.status->mid_q.next, pop);
-        e0 = __shfl(e0, 0, 64);
+        uint32_t e0 = (blockIdx.x * (uint32_t)(kSlowThreads / 64) + (uint32_t)wave_id()) * pop;
+        if (!first) {
+            if (lane == 0) e0 = n_waves * pop + atomicAdd(&W.status->mid_q.next, pop);
+            e0 = __shfl(e0, 0, 64);
+        }
+        first = false;
         if (e0 >= n_slow) break;
         const uint32_t e = e0 + lane;
         const bool in = lane < pop && e < n_slow;
@@ -1599,6 +1605,8 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
     if (W.status->flags & kBadOffsets) return;
     const int tid = threadIdx.x;
     const uint32_t n_big = W.status->slow_q.count;  // final: mid_kernel has run
+    if (blockIdx.x >= n_big) return;
+    bool first = true;  // the first entry needs no counter: workgroup g starts at g
     // Entries of known, moderate length were mid_kernel's; the rest, a workgroup per entry:
     // The entries differ in length by three orders of magnitude, so they are handed out one at a time from a counter
     // (a fixed split left the workgroup with the longest entries running long after the others).  Every workgroup
@@ -1606,7 +1614,8 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
 #pragma unroll 1
     for (;;) {
         __syncthreads();
-        if (tid == 0) ivars[1] = (int)atomicAdd(&W.status->slow_q.next, 1u);
+        if (tid == 0) ivars[1] = first ? (int)blockIdx.x : (int)(gridDim.x + atomicAdd(&W.status->slow_q.next, 1u));
+        first = false;
         __syncthreads();
         if ((uint32_t)ivars[1] >= n_big) break;
         const uint64_t ei = W.slow[(uint32_t)ivars[1]].pad;
