@@ -224,6 +224,32 @@ def test_long_runs(ctx, oracle):
     check_batch(ctx, oracle, docs, True, True, "long runs as one batch")
 
 
+def test_moderate_length_pretokens(ctx, oracle):
+    # single pre-tokens of 60..1,600 bytes: the lane-per-entry merge ends at 64 bytes, a wave per entry takes over up
+    # to 512 source bytes (its LDS arena holds 512 symbols: more, from invalid bytes at three symbols each, go to the
+    # HBM scratch), a workgroup per entry beyond; whole-string vocabulary entries reach 128 bytes
+    rng = random.Random(77)
+    lens = sorted(set(list(range(60, 70)) + list(range(124, 134)) + list(range(168, 176)) + list(range(188, 198)) +
+                      list(range(252, 260)) + list(range(506, 520)) + [300, 384, 447, 600, 683, 767, 1023, 1025, 1536, 1600]))
+    cjk = [chr(c).encode() for c in range(0x4E00, 0x9FA6)]
+    units = [b"a", b"ab", b"abc", b" ", b"-", b"=", b"/", b"#", b"*", b".", b"_", b"\xff", b"\xc3\xa9", b"\xe4\xb8\xad",
+             b"\xf0\x9f\x98\x80", b"\xe3\x80\x80", b"\xe2\x94\x80", b"\xd0\xb0"]
+    docs = []
+    for n in lens:
+        for u in units:
+            docs.append((u * (n // len(u) + 1))[:n // len(u) * len(u)])
+        docs.append(b"".join(rng.choice(cjk) for _ in range(n // 3)))                       # random ideographs
+        docs.append(bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(n)))     # one long "word"
+        docs.append(bytes(rng.choice([0x61, 0x62, 0xFF, 0xC3, 0x80]) for _ in range(n)))    # letters + invalid bytes
+        docs.append(bytes(rng.randrange(128, 256) for _ in range(n)))                       # mostly invalid
+    for bos, eos in ((True, True), (False, False)):
+        check_batch(ctx, oracle, docs, bos, eos, "moderate lengths as one batch")
+    for i in range(0, len(docs), 97):
+        check_batch(ctx, oracle, [docs[i]], True, True, "moderate length, document %d alone" % i)
+    joined = [b" ".join(docs[i:i + 50]) for i in range(0, len(docs), 50)]
+    check_batch(ctx, oracle, joined, True, True, "moderate lengths, 50 per document")
+
+
 def test_more_deferred_pretokens_than_a_tile_remembers(ctx, oracle):
     # > 1,024 short and > 256 slow deferred pre-tokens inside one 3,840-byte tile (the tile kernel's LDS lists overflow)
     rng = random.Random(5)
