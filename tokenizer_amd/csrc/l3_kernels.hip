@@ -1123,12 +1123,22 @@ __device__ __forceinline__ void lane_finish(const Workspace& W, const uint32_t* 
     if (act && tail && sum) atomicAdd(&W.tile_extra[tile], sum);
 }
 
-__global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspace W, EncodeArgs A) {
-    __shared__ uint32_t sy_a[kMergeArena];
-    __shared__ uint32_t pq_a[kMergeArena];
+struct MidLds;
+__device__ void mid_pass(const Tables& T, const Workspace& W, const EncodeArgs& A, MidLds* mid, uint32_t block, uint32_t n_blocks);
+
+// Workgroups [0, n_merge_blocks) merge the short entries; the workgroups behind them run mid_pass() on the slow list
+// (same launch: a launch of its own would cost every batch 4 us, and this kernel's registers are not what limits it).
+__global__ __launch_bounds__(kMergeThreads, 4) void merge_kernel(Tables T, Workspace W, EncodeArgs A, uint32_t n_merge_blocks) {
+    __shared__ __align__(16) uint32_t arena[2 * kMergeArena];
+    uint32_t* const sy_a = arena;
+    uint32_t* const pq_a = arena + kMergeArena;
     __shared__ uint8_t byte_tok[256];
     __shared__ uint32_t tmp[16];
     if (W.status->flags & kBadOffsets) return;
+    if (blockIdx.x >= n_merge_blocks) {
+        mid_pass(T, W, A, reinterpret_cast<MidLds*>(arena), blockIdx.x - n_merge_blocks, gridDim.x - n_merge_blocks);
+        return;
+    }
     const int tid = threadIdx.x;
     for (int i = tid; i < 256; i += kMergeThreads) byte_tok[i] = T.byte_tok[i];
     // Windows of 256 entries over all shards, longest length class first (its windows take longest); workgroup b
@@ -1145,7 +1155,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(Tables T, Workspac
     __syncthreads();
     const uint32_t n_win = win0[kMissShards];
 #pragma unroll 1
-    for (uint32_t w = blockIdx.x; w < n_win; w += gridDim.x) {
+    for (uint32_t w = blockIdx.x; w < n_win; w += n_merge_blocks) {
         uint32_t lo = 0, hi = kMissShards - 1;   // last i with win0[i] <= w (empty shards share a value: take the last)
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
@@ -1531,23 +1541,23 @@ __device__ void mid_entry(const Tables& T, const Workspace& W, const EncodeArgs&
 // notes the others for slow_kernel (Status::slow_q).  Room in the slow pool is reserved once per visit, one token
 // per symbol of the entries taken (a returning atomic per entry on the one counter queued up: 0.3 ms for 58 k entries).
 constexpr int kMidPop = 8;
-__global__ __launch_bounds__(kSlowThreads) void mid_kernel(Tables T, Workspace W, EncodeArgs A) {
-    __shared__ __align__(16) MidLds mid[kSlowThreads / 64];
-    if (W.status->flags & kBadOffsets) return;
+static_assert(kMergeThreads == kSlowThreads, "mid_pass runs inside merge_kernel's launch");
+static_assert(sizeof(MidLds) * (kSlowThreads / 64) <= 2 * kMergeArena * sizeof(uint32_t), "mid_pass uses merge_kernel's arena");
+__device__ void mid_pass(const Tables& T, const Workspace& W, const EncodeArgs& A, MidLds* mid, uint32_t block, uint32_t n_blocks) {
     uint64_t n_slow = W.status->slow_count;
     if (n_slow > W.slow_cap) n_slow = W.slow_cap;
     const uint32_t lane = (uint32_t)lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     MidLds& M = mid[wave_id()];
     // entries per visit to the counter: few enough that every wave of the grid gets some, at most kMidPop
-    uint32_t pop = (uint32_t)(n_slow / ((uint64_t)gridDim.x * (kSlowThreads / 64)));
+    uint32_t pop = (uint32_t)(n_slow / ((uint64_t)n_blocks * (kSlowThreads / 64)));
     pop = pop < 1u ? 1u : pop > (uint32_t)kMidPop ? (uint32_t)kMidPop : pop;
     // the first visit needs no counter: wave g starts at g * pop (an empty or short list costs no atomics at all)
-    const uint32_t n_waves = gridDim.x * (uint32_t)(kSlowThreads / 64);
+    const uint32_t n_waves = n_blocks * (uint32_t)(kSlowThreads / 64);
     bool first = true;
 #pragma unroll 1
     for (;;) {
-        uint32_t e0 = (blockIdx.x * (uint32_t)(kSlowThreads / 64) + (uint32_t)wave_id()) * pop;
+        uint32_t e0 = (block * (uint32_t)(kSlowThreads / 64) + (uint32_t)wave_id()) * pop;
         if (!first) {
             if (lane == 0) e0 = n_waves * pop + atomicAdd(&W.status->mid_q.next, pop);
             e0 = __shfl(e0, 0, 64);
@@ -2243,6 +2253,8 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         hipLaunchKernelGGL(tile_kernel, dim3((uint32_t)n_tiles), dim3(kTileThreads), 0, stream, T, W, A);
         L3_LAUNCH_CHECK();
         L3_EV(kEvTile);
+        uint64_t sgrid = W.slow_cap < 2048 ? W.slow_cap : 2048;
+        if (sgrid == 0) sgrid = 1;
         {
             uint64_t mgrid = ((W.miss_shard_cap + kMergeThreads - 1) / kMergeThreads) * kMissShards;  // windows at most
 #ifndef L3_MERGE_GRID
@@ -2250,14 +2262,11 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
 #endif
             if (mgrid > L3_MERGE_GRID) mgrid = L3_MERGE_GRID;
             if (mgrid == 0) mgrid = 1;
-            hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)mgrid), dim3(kMergeThreads), 0, stream, T, W, A);
+            hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)(mgrid + sgrid)), dim3(kMergeThreads), 0, stream, T, W, A,
+                               (uint32_t)mgrid);
             L3_LAUNCH_CHECK();
         }
         L3_EV(kEvMerge);
-        uint64_t sgrid = W.slow_cap < 2048 ? W.slow_cap : 2048;
-        if (sgrid == 0) sgrid = 1;
-        hipLaunchKernelGGL(mid_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A);
-        L3_LAUNCH_CHECK();
         hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A);
         L3_LAUNCH_CHECK();
         L3_EV(kEvSlow);
