@@ -632,7 +632,9 @@ static void encode_plain_segment(const l3o_tokenizer* t, cache_ref* cr, const ui
 }
 
 static void encode_impl(const l3o_tokenizer* t, cache_ref* cr, const uint8_t* text, size_t n, int bos, int eos, ivec* out) {
-    if (bos) ivec_push(out, 128000);                                  /* GetSpecialTokenID("<|begin_of_text|>") */
+    /* GetSpecialTokenID (tokenizer.go:226,259,357-368): a lookup, so the ids follow the size of the base vocabulary */
+    int32_t bos_id = 0, eos_id = 0;
+    if (bos && bmap_get(&t->token_lookup, (const uint8_t*)"<|begin_of_text|>", 17, &bos_id)) ivec_push(out, bos_id);
     /* SplitBySpecialTokens (special.go:48-83) fused with the loop at tokenizer.go:234-255 */
     size_t last = 0, i = 0;
     while (i < n) {
@@ -645,7 +647,7 @@ static void encode_impl(const l3o_tokenizer* t, cache_ref* cr, const uint8_t* te
         i += ml; last = i;
     }
     if (last < n) encode_plain_segment(t, cr, text + last, n - last, out);
-    if (eos) ivec_push(out, 128001);
+    if (eos && bmap_get(&t->token_lookup, (const uint8_t*)"<|end_of_text|>", 15, &eos_id)) ivec_push(out, eos_id);
 }
 
 int64_t l3o_encode(l3o_tokenizer* t, const uint8_t* text, size_t n, int bos, int eos, int32_t* out, size_t cap) {

@@ -13,7 +13,7 @@ DATA = os.path.join(ROOT, "tokenizer_amd", "data")
 
 
 class HostShim:
-    def __init__(self):
+    def __init__(self, vocab=None, merges=None):
         srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cpp"))]
         if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
             subprocess.check_call(["make", "-C", CSRC, "-s", "hosttest"])
@@ -36,8 +36,9 @@ class HostShim:
         L.l3t_bpe_rounds.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
         L.l3t_token_bytes.restype = C.c_int64
         L.l3t_token_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
-        vocab = open(os.path.join(DATA, "vocab_base64.txt"), "rb").read()
-        merges = open(os.path.join(DATA, "merges_binary.txt"), "rb").read()
+        if vocab is None or merges is None:
+            vocab = open(os.path.join(DATA, "vocab_base64.txt"), "rb").read()
+            merges = open(os.path.join(DATA, "merges_binary.txt"), "rb").read()
         self.h = L.l3t_create(vocab, len(vocab), merges, len(merges))
         assert self.h
 

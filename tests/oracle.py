@@ -24,7 +24,8 @@ def build_oracle():
 
 
 class Oracle:
-    def __init__(self):
+    def __init__(self, vocab=None, merges=None):
+        """vocab / merges: the contents of custom data files (WithDataFiles); default: the shipped Llama-3 files."""
         self.lib = C.CDLL(build_oracle())
         L = self.lib
         L.l3o_new.restype = C.c_void_p
@@ -50,8 +51,9 @@ class Oracle:
         L.l3o_encode_batch.restype = C.c_int64
         L.l3o_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
                                        C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
-        vocab = open(os.path.join(DATA, "vocab_base64.txt"), "rb").read()
-        merges = open(os.path.join(DATA, "merges_binary.txt"), "rb").read()
+        if vocab is None or merges is None:
+            vocab = open(os.path.join(DATA, "vocab_base64.txt"), "rb").read()
+            merges = open(os.path.join(DATA, "merges_binary.txt"), "rb").read()
         self.h = L.l3o_new(vocab, len(vocab), merges, len(merges))
         assert self.h, "oracle failed to load the vocabulary data"
 

@@ -159,6 +159,8 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     W.pool_cap = c->pool_cap;
     W.mpool_shard_cap = c->mpool_shard_cap;
     W.scratch_cap = c->scratch_cap;
+    W.bos_id = c->H.special_id[0];  // canonical index 0 / 1 = <|begin_of_text|> / <|end_of_text|> (l3_tables.cpp)
+    W.eos_id = c->H.special_id[1];
     return L3_OK;
 }
 

@@ -14,8 +14,6 @@ namespace l3 {
 // ---- vocabulary facts (reference: llama3/constants.go:6-10, internal/tokens/special.go:19-40)
 constexpr int kBaseVocab = 128000;
 constexpr int kNumSpecial = 256;
-constexpr int kBosId = 128000;  // <|begin_of_text|>
-constexpr int kEosId = 128001;  // <|end_of_text|>
 constexpr int kMaxSpecialLen = 30;  // "<|reserved_special_token_247|>"
 constexpr int kMaxTokenBytes = 128; // longest vocabulary entry (raw bytes)
 

@@ -102,6 +102,7 @@ struct alignas(32) TileRec {
 };
 
 struct Workspace {
+    int32_t bos_id, eos_id;  // ids of <|begin_of_text|> / <|end_of_text|> in this vocabulary (tokenizer.go:226,259: looked up, not constants)
     int32_t* stream;        // [n_tiles * kTileCap] per-tile token stream incl. slow placeholders
     uint32_t* tile_items;   // [n_tiles] items in the tile's stream
     uint32_t* tile_extra;   // [n_tiles] sum of (tokens - 1) over the tile's deferred pre-tokens (atomic adds)

@@ -2006,8 +2006,8 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
             if (i <= n_items && ((dbits >> j) & 1u)) {   // a document starts here (tokenizer.go:225-229,258-262)
                 const uint64_t d = d_lo + dp - 1;
                 A.out_off[d] = base + tp + d * be;
-                if (bos && d < A.n_docs) stg[rel - bos] = kBosId;
-                if (eos && d > 0) stg[rel - bos - 1] = kEosId;
+                if (bos && d < A.n_docs) stg[rel - bos] = W.bos_id;
+                if (eos && d > 0) stg[rel - bos - 1] = W.eos_id;
             }
             if (i < n_items) {
                 if (item[j] >= 0) {
@@ -2109,8 +2109,8 @@ __device__ void emit_tile_generic(const Workspace& W, const EncodeArgs& A, uint6
     for (uint64_t d = d_lo + tid; d < d_hi; d += kTileThreads) {
         const uint64_t off = base + tokpre[W.doc_item[d]] + d * be;
         A.out_off[d] = off;
-        if (bos && d < A.n_docs) A.out_tok[off] = kBosId;
-        if (eos && d > 0) A.out_tok[off - 1] = kEosId;
+        if (bos && d < A.n_docs) A.out_tok[off] = W.bos_id;
+        if (eos && d > 0) A.out_tok[off - 1] = W.eos_id;
     }
     // long runs of tokens from the pool: copied by the whole workgroup (a pre-token with more than 64
     // tokens has more than 21 bytes, so one tile holds fewer than kEmitQueue of them)
