@@ -3,21 +3,23 @@
 // Replaces the loops of llama3.Tokenizer.Encode (reference llama3/tokenizer.go:217-265) for a
 // batch of documents held as one concatenated byte array + offsets:
 //
-//   validate/docs  doc_off sanity; first document of every tile
-//   tile_kernel    one workgroup per 4 KiB of text (+ halos) staged in LDS:
-//                  UTF-8 decode + character class per byte      (state_machine.go:36,310-320)
+//   docs_kernel    doc_off sanity; first document of every tile; clears the per-tile counters
+//   tile_kernel    one workgroup per 3,840 bytes of text (+ halos) staged in LDS:
+//                  UTF-8 validity + character class per byte    (state_machine.go:36,310-320)
 //                  special-token literals                       (special.go:12,48-83)
 //                  position-local start-of-pre-token predicate  (state_machine.go:82-284, l3_rules.h)
 //                  whole-pre-token vocabulary probe             (bpe.go:27-33)
-//                  in-LDS greedy merge, one lane per pre-token  (bpe.go:36-71)
-//                  compaction of the surviving ids into the tile's token stream
-//   slow_kernel    one workgroup per pre-token the tile kernel deferred (invalid UTF-8, long, or
-//                  ending beyond the halo): exact round-based parallel greedy merge
-//   scan_kernel    exclusive scan of per-tile token totals
+//                  one stream item per pre-token: its id, or a placeholder of a deferred pre-token
+//   merge_kernel   one lane per short deferred pre-token (<= 64 bytes): greedy merge in an LDS slot (bpe.go:36-71);
+//                  its last workgroups make the wave-per-entry pass over the slow list (mid_pass)
+//   slow_kernel    one workgroup per remaining deferred pre-token (long, or ending beyond the halo): exact
+//                  round-based parallel greedy merge
+//   block_totals_kernel, scan_kernel   per-tile output bases: totals per 1,024 tiles, their exclusive scan
+//                  (one launch with the last workgroup scanning was tried: no faster, two fences more)
 //   emit_kernel    scatter to the final token array, per-document offsets, BOS/EOS (tokenizer.go:225-262)
 //
 // All cross-workgroup data flows through kernel boundaries on one stream; atomics are used only
-// for counters that later kernels read.
+// for counters / appends that later kernels read.
 #include "l3_kernels.h"
 
 #include "l3_bpe.h"
