@@ -166,7 +166,7 @@ def main():
             ns = min(args.cpu_sample_docs, n_docs)
             oracle = Oracle()
             s_text, s_off = text[:ns * DOC_BYTES], off[:ns + 1]
-            passes = 8
+            passes = 24  # about 30 core-seconds of CPU work on 16 threads
             c0 = time.perf_counter()
             for _ in range(passes):  # one tokenizer, its pre-token caches persist as the reference's default cache does
                 exp_tok, exp_off = oracle.encode_batch(s_text, s_off, True, True, threads=threads)
@@ -178,7 +178,7 @@ def main():
                                       "sample": "%d passes over the first %d documents (%d MiB) of the same C2 shard; C restatement "
                                                 "of the reference algorithm, document-per-thread work queue, per-thread "
                                                 "pre-token caches kept across passes" % (passes, ns, ns * DOC_BYTES >> 20),
-                                      "seconds": cdt, "input_gb_per_s": passes * ns * DOC_BYTES / cdt / 1e9}
+                                      "seconds": cdt, "core_seconds": cdt * threads, "input_gb_per_s": passes * ns * DOC_BYTES / cdt / 1e9}
             result["parity_vs_oracle_on_sample"] = parity
             if not parity:
                 result["error"] = "GPU output differs from the oracle on the CPU-baseline sample"
