@@ -1286,6 +1286,10 @@ __device__ __forceinline__ unsigned long long group_min64(unsigned long long v, 
         return block_min64(v, tmp64);
     }
 }
+#ifndef L3_ROUND_U
+#define L3_ROUND_U 1
+#endif
+constexpr int kRoundU = L3_ROUND_U;  // elements per thread and step in the probing sweeps of a round
 template <bool WAVE>
 __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, int32_t*& sb, uint32_t*& pb, uint32_t n,
                                  uint32_t* tmp, unsigned long long* tmp64, Seg* segtmp) {
@@ -1362,36 +1366,56 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
             }
         }
         group_sync<WAVE>();
-        // (c) theta
+        // (c) theta.  Everything an element needs is loaded up front (clamped indices, no branches), then its two
+        // probes together.  kRoundU elements per thread and step can be batched that way; measured on C3, 2 and 4 are
+        // slower than 1 (registers: 201 VGPRs at 4 halve the occupancy), so 1 it is.
         unsigned long long th = ~0ull;
-        for (uint32_t i = tid; i < n; i += kGroup) {
-            const uint32_t p = pa[i];
-            if (p == kNoPrio) continue;
-            const unsigned long long key = ((unsigned long long)p << 32) | i;
-            if (!(sa[i] & kSelBit)) {
-                const bool covered = (i >= 1 && (sa[i - 1] & kSelBit) && pa[i - 1] <= p) || ((sa[i + 1] & kSelBit) && pa[i + 1] < p);
-                if (!covered) th = key < th ? key : th;
-                continue;
+        for (uint32_t i0 = tid; i0 < n; i0 += kGroup * kRoundU) {
+            uint32_t pv[kRoundU], m[kRoundU];
+            unsigned long long key[kRoundU], k1[kRoundU], k2[kRoundU];
+            bool sel[kRoundU], hasl[kRoundU], hasr[kRoundU];
+            PairBucket u1[kRoundU], v1[kRoundU], u2[kRoundU], v2[kRoundU];
+#pragma unroll
+            for (int k = 0; k < kRoundU; k++) {
+                const uint32_t i = i0 + (uint32_t)k * kGroup;
+                const bool in = i < n;
+                const uint32_t ii = in ? i : n - 1u;
+                const uint32_t im1 = ii >= 1u ? ii - 1u : 0u, im2 = ii >= 2u ? ii - 2u : 0u;
+                const uint32_t ip1 = ii + 1u < n ? ii + 1u : n - 1u, ip2 = ii + 2u < n ? ii + 2u : n - 1u;
+                const uint32_t p = pa[ii], pm1 = pa[im1], pm2 = pa[im2], pp1 = pa[ip1], pp2 = pa[ip2];
+                const int32_t s0 = sa[ii], sm1 = sa[im1], sm2 = sa[im2], sp1 = sa[ip1], sp2 = sa[ip2];
+                const bool valid = in && p != kNoPrio;   // then i + 1 < n: pa[n - 1] is kNoPrio
+                sel[k] = valid && (s0 & kSelBit);
+                pv[k] = p;
+                key[k] = ((unsigned long long)p << 32) | i;
+                const bool covered = (i >= 1u && (sm1 & kSelBit) && pm1 <= p) || ((sp1 & kSelBit) && pp1 < p);
+                if (valid && !sel[k] && !covered) th = key[k] < th ? key[k] : th;
+                m[k] = prio_merged_id(p);
+                hasl[k] = sel[k] && i >= 1u;
+                hasr[k] = sel[k] && i + 2u < n;
+                uint32_t lsym = (uint32_t)(sm1 & kIdMask);
+                if (i >= 2u && (sm2 & kSelBit) && pm2 <= p) lsym = prio_merged_id(pm2);
+                uint32_t rsym = (uint32_t)(sp2 & kIdMask);
+                if ((sp2 & kSelBit) && pp2 < p) rsym = prio_merged_id(pp2);
+                const uint32_t a1 = hasl[k] ? lsym : 0u, b1 = hasl[k] ? m[k] : 0u;   // idle lanes probe (0, 0)
+                const uint32_t a2 = hasr[k] ? m[k] : 0u, b2 = hasr[k] ? rsym : 0u;
+                k1[k] = pair_key(a1, b1);
+                k2[k] = pair_key(a2, b2);
+                uint32_t h1, h2, h3, h4;
+                pair_hash2(a1, b1, T.pair_log2, &h1, &h2);
+                pair_hash2(a2, b2, T.pair_log2, &h3, &h4);
+                u1[k] = T.pair_buckets[h1]; v1[k] = T.pair_buckets[h2];
+                u2[k] = T.pair_buckets[h3]; v2[k] = T.pair_buckets[h4];
             }
-            const uint32_t m = prio_merged_id(p);
-            const bool hasl = i >= 1, hasr = i + 2 < n;
-            uint32_t lsym = 0, rsym = 0;
-            if (hasl) {
-                lsym = (uint32_t)(sa[i - 1] & kIdMask);
-                if (i >= 2 && (sa[i - 2] & kSelBit) && pa[i - 2] <= p) lsym = prio_merged_id(pa[i - 2]);
+#pragma unroll
+            for (int k = 0; k < kRoundU; k++) {
+                const uint32_t r1 = hasl[k] ? pair_pick(k1[k], u1[k], v1[k]) : kNoPrio;
+                const uint32_t r2 = hasr[k] ? pair_pick(k2[k], u2[k], v2[k]) : kNoPrio;
+                const uint32_t v = r2 < r1 ? r2 : r1;
+                unsigned long long beta = v == kNoPrio ? ~0ull : ((unsigned long long)v << 32);
+                if (beta < key[k] + 1) beta = key[k] + 1;
+                if (sel[k]) th = beta < th ? beta : th;
             }
-            if (hasr) {
-                rsym = (uint32_t)(sa[i + 2] & kIdMask);
-                if ((sa[i + 2] & kSelBit) && pa[i + 2] < p) rsym = prio_merged_id(pa[i + 2]);
-            }
-            uint32_t v1, v2;
-            pair_prio2(T, lsym, m, m, rsym, &v1, &v2);  // both probes in flight together
-            if (!hasl) v1 = kNoPrio;
-            if (!hasr) v2 = kNoPrio;
-            const uint32_t v = v2 < v1 ? v2 : v1;
-            unsigned long long beta = v == kNoPrio ? ~0ull : ((unsigned long long)v << 32);
-            if (beta < key + 1) beta = key + 1;
-            th = beta < th ? beta : th;
         }
         th = group_min64<WAVE>(th, tmp64);
         // (d) apply the members of S below theta, compacting into the other buffer
@@ -1430,18 +1454,43 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
             j0 += (uint32_t)__popcll(lm);
         }
         group_sync<WAVE>();
-        // (e) re-probe the pairs that touch a merged symbol; the smallest key of the next round on the way
+        // (e) re-probe the pairs that touch a merged symbol (batched like (c)); the smallest key of the next round
+        // on the way
         best = ~0ull;
-        for (uint32_t q = tid; q < n2; q += kGroup) {
-            const int32_t x = sb[q];
-            const int32_t y = q + 1 < n2 ? sb[q + 1] : 0;
-            uint32_t p = pb[q];
-            if ((x | y) & kDirtyBit) {
-                p = q + 1 < n2 ? pair_prio(T, (uint32_t)(x & kIdMask), (uint32_t)(y & kIdMask)) : kNoPrio;
-                pb[q] = p;
+        for (uint32_t q0 = tid; q0 < n2; q0 += kGroup * kRoundU) {
+            uint32_t pv[kRoundU];
+            unsigned long long kk[kRoundU];
+            bool in[kRoundU], dirty[kRoundU], probe[kRoundU];
+            PairBucket u[kRoundU], v[kRoundU];
+#pragma unroll
+            for (int k = 0; k < kRoundU; k++) {
+                const uint32_t q = q0 + (uint32_t)k * kGroup;
+                in[k] = q < n2;
+                const uint32_t qq = in[k] ? q : n2 - 1u;
+                const bool nxt = qq + 1u < n2;
+                const int32_t x = sb[qq];
+                const int32_t y = nxt ? sb[qq + 1u] : 0;
+                pv[k] = pb[qq];
+                dirty[k] = in[k] && ((x | y) & kDirtyBit);
+                probe[k] = dirty[k] && nxt;
+                const uint32_t a = probe[k] ? (uint32_t)(x & kIdMask) : 0u, b = probe[k] ? (uint32_t)(y & kIdMask) : 0u;
+                kk[k] = pair_key(a, b);
+                uint32_t h1, h2;
+                pair_hash2(a, b, T.pair_log2, &h1, &h2);
+                u[k] = T.pair_buckets[h1];
+                v[k] = T.pair_buckets[h2];
             }
-            const unsigned long long v = ((unsigned long long)p << 32) | q;
-            best = v < best ? v : best;
+#pragma unroll
+            for (int k = 0; k < kRoundU; k++) {
+                const uint32_t q = q0 + (uint32_t)k * kGroup;
+                uint32_t p = pv[k];
+                if (dirty[k]) {
+                    p = probe[k] ? pair_pick(kk[k], u[k], v[k]) : kNoPrio;
+                    pb[q] = p;
+                }
+                const unsigned long long val = ((unsigned long long)p << 32) | q;
+                if (in[k]) best = val < best ? val : best;
+            }
         }
         best = group_min64<WAVE>(best, tmp64);
         { int32_t* t = sa; sa = sb; sb = t; }
