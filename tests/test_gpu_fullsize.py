@@ -68,6 +68,25 @@ def test_c4_pathological_1mib(ctx, oracle):
     _same(ctx, oracle, t, o)
 
 
+def test_long_digit_runs_are_linear(ctx, oracle):
+    # every tile inside a digit run needs the run's length before it (1-3 digit grouping, state_machine.go:178-191);
+    # tiles pass it on (Workspace::tile_digits), so 16 MiB of digits must not take 256 times as long as 1 MiB
+    from tokenizer_amd import capi
+    rng = np.random.default_rng(12)
+    ascii_run = rng.integers(48, 58, 16 << 20, dtype=np.uint8).tobytes()
+    mixed = ("12٣٤٥" * 50000 + "7" * 400001 + "٣" * 300000 + " x " + "9" * 100000).encode()
+    docs = [ascii_run, b"ab" + ascii_run[:5000001], mixed, b"1" * 3839, b"1" * 3841, b"22" + "٣".encode() * 7000]
+    ctx.set_profiling(True)
+    for i, d in enumerate(docs):
+        text, off = capi.pack_docs([d])
+        _same(ctx, oracle, text, off, threads=1)
+        if i == 0:
+            assert ctx.last_timings()["tile"] < 20.0, ctx.last_timings()     # quadratic: ~900 ms
+    text, off = capi.pack_docs(docs)
+    _same(ctx, oracle, text, off)
+    ctx.set_profiling(False)
+
+
 def test_host_batches_in_pieces(ctx, oracle):
     """l3_encode_batch moves batches of >= 16 MiB in pieces of whole documents (overlapped copies): same result as
     the device-pointer entry point in one pass, ragged documents included, and the capacity protocol still holds."""

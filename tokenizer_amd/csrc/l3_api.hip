@@ -117,7 +117,7 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     const uint64_t n_tiles = num_tiles(n_bytes);
     HIPCHK(c, c->w_stream.ensure(n_tiles * kTileCap * sizeof(int32_t)));
     HIPCHK(c, c->w_items.ensure(n_tiles * 4));
-    HIPCHK(c, c->w_extra.ensure(n_tiles * 4));
+    HIPCHK(c, c->w_extra.ensure(n_tiles * 8));  // tile_extra + tile_digits
     HIPCHK(c, c->w_base.ensure((n_tiles / 1024 + 2) * 8));
     HIPCHK(c, c->w_pre.ensure(n_tiles * sizeof(TileRec)));
     HIPCHK(c, c->w_flag.ensure(n_tiles * 4));
@@ -143,6 +143,7 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     W.stream = c->w_stream.as<int32_t>();
     W.tile_items = c->w_items.as<uint32_t>();
     W.tile_extra = c->w_extra.as<uint32_t>();
+    W.tile_digits = W.tile_extra + n_tiles;
     W.tile_base = c->w_base.as<uint64_t>();
     W.tile_rec = c->w_pre.as<TileRec>();
     W.tile_flag = c->w_flag.as<uint32_t>();

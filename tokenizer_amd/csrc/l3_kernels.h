@@ -106,6 +106,8 @@ struct Workspace {
     int32_t* stream;        // [n_tiles * kTileCap] per-tile token stream incl. slow placeholders
     uint32_t* tile_items;   // [n_tiles] items in the tile's stream
     uint32_t* tile_extra;   // [n_tiles] sum of (tokens - 1) over the tile's deferred pre-tokens (atomic adds)
+    uint32_t* tile_digits;  // [n_tiles] 0, or 1 + the number of decimal-digit runes right before the tile start (a tile that had to
+                            // count them leaves the figure for the tiles after it: see digits_before_global)
     uint64_t* tile_base;    // [ceil(n_tiles / 1024)] exclusive scan of the token totals of blocks of 1024 tiles
     TileRec* tile_rec;      // [n_tiles] what the emit kernels need to know about a tile, in one 32-byte load
     uint32_t* tile_flag;    // [n_tiles] 1 = the fast emit kernel left the tile to the generic one

@@ -198,10 +198,14 @@ __device__ __forceinline__ int find_next_bit(const uint32_t* bits, int from, int
     }
 }
 
-// number of consecutive Nd runes immediately before global position `pos` inside [seg_lo, seg_hi)
-// (whole workgroup; pathological digit runs longer than the look-behind halo only)
+// number of consecutive Nd runes immediately before global position `pos` (= the start of tile `tile`) inside
+// [seg_lo, seg_hi)  (whole workgroup; pathological digit runs longer than the look-behind halo only).
+// Every tile of a long digit run asks this question, and answering it by walking back to the start of the run is
+// quadratic in the run length.  So a tile leaves its answer in memo[tile] (1 + count; 0 = none), and a walk that
+// arrives at the start of an earlier tile takes that tile's answer if it is there already: tiles are dispatched in
+// order, so it nearly always is, and a walk is one tile long.  Nobody waits: a missing answer only means walking on.
 __device__ uint32_t digits_before_global(const uint8_t* text, int64_t seg_lo, int64_t seg_hi, int64_t pos,
-                                         const Tables& T, unsigned long long* tmp /* 8 words */) {
+                                         const Tables& T, unsigned long long* tmp /* 8 words */, uint32_t* memo, uint64_t tile) {
     GlobalSrc gs{text, seg_lo, seg_hi};
     uint32_t total = 0;
     int64_t hi = pos;
@@ -230,7 +234,16 @@ __device__ uint32_t digits_before_global(const uint8_t* text, int64_t seg_lo, in
         __syncthreads();
         if (found) break;
         hi -= kTileThreads;
+        if (hi > seg_lo && (pos - hi) % kTile == 0) {  // the start of an earlier tile of the same document
+            if (threadIdx.x == 0)
+                tmp[0] = __hip_atomic_load(&memo[tile - (uint64_t)((pos - hi) / kTile)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const uint32_t known = (uint32_t)tmp[0];
+            __syncthreads();
+            if (known) { total += known - 1u; break; }
+        }
     }
+    if (threadIdx.x == 0) __hip_atomic_store(&memo[tile], total + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return total;
 }
 
@@ -240,7 +253,7 @@ __device__ uint32_t digits_before_global(const uint8_t* text, int64_t seg_lo, in
 // are, and all later kernels return at once when kBadOffsets is set.
 __global__ void docs_kernel(Workspace W, EncodeArgs A, uint64_t n_tiles) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint64_t t = gid; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) W.tile_extra[t] = 0;
+    for (uint64_t t = gid; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) { W.tile_extra[t] = 0; W.tile_digits[t] = 0; }
     const uint64_t d = gid;
     if (d > A.n_docs) return;
     const uint64_t off = A.doc_off[d];
@@ -671,7 +684,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             const bool at_doc_start = (R.bm[B_DS][own_lo >> 6] >> (own_lo & 63)) & 1ull;
             if (!at_doc_start) {
                 int64_t seg_lo = (int64_t)A.doc_off[d0 - 1], seg_hi = (int64_t)A.doc_off[d0];
-                edge = digits_before_global(A.text, seg_lo, seg_hi, (int64_t)t_lo, T, tmp64);
+                edge = digits_before_global(A.text, seg_lo, seg_hi, (int64_t)t_lo, T, tmp64, W.tile_digits, tile);
             }
         }
         __syncthreads();
