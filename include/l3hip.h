@@ -78,6 +78,14 @@ int l3_vocab_size(const l3_ctx* ctx);
 /* raw bytes of one token (what Decode appends for it); returns its length or L3_E_NOT_FOUND */
 int l3_token_bytes(const l3_ctx* ctx, int32_t id, uint8_t* out, size_t cap);
 
+/* Page-locked host memory for batch buffers (no counterpart in the reference: Go slices live on the Go heap, which is
+ * pageable).  l3_encode_batch moves a batch whose text and out_tok both lie in memory from l3_host_alloc in overlapped
+ * pieces (about 3.5 times the host-fed rate of pageable buffers); a cgo shim allocates its batch text and token
+ * buffers here once and reuses them.  The memory belongs to the caller until l3_host_free; the context is only needed
+ * to select the device. */
+int l3_host_alloc(l3_ctx* ctx, size_t bytes, void** out);
+int l3_host_free(l3_ctx* ctx, void* p);
+
 /* Measurement support (no counterpart in the reference): when enabled, HIP events are recorded on the
  * launch stream between the kernels of every encode call; l3_last_timings() returns the milliseconds of
  * the last call: [0] validate+docs, [1] tile kernel, [2] merge kernel, [3] slow kernel, [4] scan, [5] emit,

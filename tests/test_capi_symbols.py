@@ -29,5 +29,8 @@ def test_create_rejects_bad_data_without_gpu():
     assert rc == capi.L3_E_DATA and not h.value
     assert b"vocabulary" in lib.l3_last_error(None)
     vocab, merges = capi.read_data_files()
-    rc = lib.l3_create(vocab, len(vocab), merges[:1000], 1000, 0, C.byref(h))
-    assert rc in (capi.L3_E_DATA, capi.L3_E_NO_DEVICE) and not h.value
+    import base64
+    bad = base64.b64encode(b"\xff" * 34)   # pairs of id 131071: not in the vocabulary (a shorter merge list would be valid data)
+    rc = lib.l3_create(vocab, len(vocab), bad, len(bad), 0, C.byref(h))
+    assert rc == capi.L3_E_DATA and not h.value
+    assert b"unknown token id" in lib.l3_last_error(None)

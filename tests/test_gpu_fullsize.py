@@ -112,6 +112,15 @@ def test_host_batches_in_pieces(ctx, oracle):
     tok, toff = p_out.numpy()[:n_p.value].copy(), p_off
     tok1, toff1 = ctx.encode_batch(base, off, True, True)   # pageable buffers: one pass
     assert np.array_equal(tok1, tok) and np.array_equal(toff1, toff)
+    # the same with buffers from the library's own allocator (what a cgo shim would use)
+    l_text = ctx.host_alloc(base.size)
+    l_text[:] = base
+    l_out = ctx.host_alloc(4 * p_out.numel(), dtype=np.int32)
+    rc = ctx.lib.l3_encode_batch(ctx.h, l_text.ctypes.data, off.ctypes.data, off.size - 1, 3, l_out.ctypes.data, l_out.size,
+                                 p_off.ctypes.data, C.byref(n_p))
+    assert rc == capi.L3_OK and n_p.value == tok.size and np.array_equal(l_out[:tok.size], tok) and np.array_equal(p_off, toff1)
+    ctx.host_free(l_text)
+    ctx.host_free(l_out)
     d_text = torch.from_numpy(base).cuda()
     d_off = torch.from_numpy(off.astype(np.int64)).cuda()
     n_docs = off.size - 1

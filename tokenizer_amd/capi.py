@@ -33,6 +33,8 @@ SYMBOLS = [
     ("l3_encode_batch_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P,
                                         C.POINTER(C.c_uint64), _P]),
     ("l3_pretokenize_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P]),
+    ("l3_host_alloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    ("l3_host_free", C.c_int, [_P, _P]),
     ("l3_decode_batch", C.c_int, [_P, _P, _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     ("l3_special_token_id", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]),
     ("l3_vocab_size", C.c_int, [_P]),
@@ -187,6 +189,23 @@ class Context:
         return rc, int(n.value)
 
     # ---- small queries ------------------------------------------------------------------------------
+    def host_alloc(self, nbytes, dtype=np.uint8):
+        """Page-locked host buffer from the library as a numpy array (free it with host_free(array))."""
+        p = _P()
+        rc = self.lib.l3_host_alloc(self.h, int(nbytes), C.byref(p))
+        if rc != L3_OK:
+            raise self._err(rc)
+        buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype)
+        self._host_allocs = getattr(self, "_host_allocs", {})
+        self._host_allocs[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a):
+        rc = self.lib.l3_host_free(self.h, C.c_void_p(self._host_allocs.pop(a.ctypes.data)))
+        if rc != L3_OK:
+            raise self._err(rc)
+
     def special_token_id(self, name: bytes):
         v = C.c_int32(0)
         rc = self.lib.l3_special_token_id(self.h, name, len(name), C.byref(v))

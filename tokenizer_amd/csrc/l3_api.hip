@@ -583,6 +583,22 @@ int l3_special_token_id(const l3_ctx* c, const char* name, size_t name_len, int3
 
 int l3_vocab_size(const l3_ctx* c) { return c ? c->H.n_tokens : L3_E_INVALID_ARG; }
 
+int l3_host_alloc(l3_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return L3_E_INVALID_ARG;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    void* p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+    *out = p;
+    return L3_OK;
+}
+
+int l3_host_free(l3_ctx* c, void* p) {
+    if (!c) return L3_E_INVALID_ARG;
+    if (p) HIPCHK(c, hipHostFree(p));
+    return L3_OK;
+}
+
 int l3_token_bytes(const l3_ctx* c, int32_t id, uint8_t* out, size_t cap) {
     if (!c) return L3_E_INVALID_ARG;
     if (id < 0 || id >= c->H.n_tokens) return L3_E_NOT_FOUND;
