@@ -222,6 +222,16 @@ def test_long_runs(ctx, oracle):
     for i, d in enumerate(docs):
         check_batch(ctx, oracle, [d], True, True, "long run %d" % i)
     check_batch(ctx, oracle, docs, True, True, "long runs as one batch")
+    # a digit run of multi-byte digits followed by ASCII digits, at every alignment to the tiles: a tile's look-behind
+    # halo may begin inside a multi-byte digit (found by tools/fuzz_soak.py: the halo then looked like the run's start)
+    docs = []
+    for digit in ("٣", "३", "\U0001d7ce"):
+        for shift in range(0, 9):
+            docs.append(b"x" * shift + digit.encode() * 1500 + b"1234567890" * 900 + b" end")
+            docs.append(b"y" * shift + digit.encode() * 1301 + b"7" * 4000 + digit.encode() * 700 + b"42" * 2100)
+    check_batch(ctx, oracle, docs, True, True, "mixed-width digit runs as one batch")
+    for i in range(0, len(docs), 7):
+        check_batch(ctx, oracle, [docs[i]], False, False, "mixed-width digit run %d alone" % i)
 
 
 def test_moderate_length_pretokens(ctx, oracle):

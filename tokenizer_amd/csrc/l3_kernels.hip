@@ -234,6 +234,7 @@ __device__ uint32_t digits_before_global(const uint8_t* text, int64_t seg_lo, in
         __syncthreads();
         if (found) break;
         hi -= kTileThreads;
+#ifndef L3_NO_DIGIT_MEMO
         if (hi > seg_lo && (pos - hi) % kTile == 0) {  // the start of an earlier tile of the same document
             if (threadIdx.x == 0)
                 tmp[0] = __hip_atomic_load(&memo[tile - (uint64_t)((pos - hi) / kTile)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -242,6 +243,7 @@ __device__ uint32_t digits_before_global(const uint8_t* text, int64_t seg_lo, in
             __syncthreads();
             if (known) { total += known - 1u; break; }
         }
+#endif
     }
     if (threadIdx.x == 0) __hip_atomic_store(&memo[tile], total + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return total;
@@ -458,7 +460,15 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int n, int own_lo, i
     u64 DST = 0;
     if (!mb) {
         u64 c2 = contN;
-        if (w == 0 && !region_at_text_start && !(SEG & 1ull)) c2 |= N & 1ull;  // unknown: assume linked
+        if (w == 0 && !region_at_text_start && !(SEG & 1ull)) {
+            c2 |= N & 1ull;  // unknown: assume linked
+            // The region may begin inside a rune whose first bytes lie before it (up to three continuation bytes):
+            // that rune may be a multi-byte digit, so a digit right after those bytes is assumed linked as well --
+            // the walk back through global memory then finds out
+            int k = 0;
+            while (k < 3 && (R.b[k] & 0xC0u) == 0x80u && !((SEG >> (k + 1)) & 1ull)) k++;
+            if (k && ((N >> k) & 1ull)) c2 |= (2ull << k) - 1ull;
+        }
         Seg sg;
         if (!(N >> 63)) { sg.cnt = 0; sg.open = 0; }
         else {
