@@ -12,6 +12,7 @@ from tests.oracle import Oracle
 from tokenizer_amd import capi
 
 rng = None
+BIG = int(os.environ.get("SOAK_BIG", "1"))   # > 1: that many times more documents per batch, runs up to 34,000 bytes
 KINDS = [int(x) for x in os.environ.get("SOAK_KINDS", "0,1,2,3,4,5,6,7,8,9").split(",")]   # which kinds of runs
 SPECIALS = [b"<|begin_of_text|>", b"<|eot_id|>", b"<|reserved_special_token_17|>", b"<|eot_id|", b"<|x|>"]
 SEPS = [b"", b"", b" ", b"\n", b"\r\n", b"  ", b"\t", b", ", b".", b"'s", b"'", b"\xe3\x80\x82"]
@@ -42,10 +43,10 @@ def run_of(kind, n):
 
 def gen_batch():
     docs = []
-    for _ in range(int(rng.integers(1, 60))):
+    for _ in range(int(rng.integers(1, 60 * BIG))):
         parts = []
         for _ in range(int(rng.integers(1, 12))):
-            n = int(2 ** rng.uniform(0, 12.55))
+            n = int(2 ** rng.uniform(0, 12.55 + (2.5 if BIG > 1 else 0.0)))
             parts.append(run_of(int(KINDS[int(rng.integers(0, len(KINDS)))]), n))
             if rng.random() < 0.05:
                 parts.append(SPECIALS[int(rng.integers(0, len(SPECIALS)))])
