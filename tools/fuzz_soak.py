@@ -58,6 +58,25 @@ def gen_batch():
     return docs, bos, eos
 
 
+def gen_corpus_batch():
+    """SOAK_MODE=corpora: the generators of the benchmark corpora at random sizes (English documents of one random size,
+    multilingual documents with a random cap on the run length), cut again at random places."""
+    from tools import corpora
+    n = int(rng.integers(1, 3000))
+    size = int(2 ** rng.uniform(0, 12))
+    text, off = corpora.english(n, size, first_doc=int(rng.integers(0, 1 << 40)))
+    parts = [text]
+    if rng.random() < 0.5:
+        m_size = int(2 ** rng.uniform(6, 19))
+        t2, _ = corpora.multilingual(int(rng.integers(1, 4)), m_size, max_run=int(2 ** rng.uniform(0, 12)), first_doc=int(rng.integers(0, 1 << 30)))
+        parts.append(t2)
+    text = np.concatenate(parts)
+    cuts = np.unique(np.concatenate([[0, text.size], rng.integers(0, text.size + 1, int(rng.integers(0, 2000)))]))
+    docs = [text[int(a):int(b)].tobytes() for a, b in zip(cuts[:-1], cuts[1:])]
+    bos, eos = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    return docs, bos, eos
+
+
 def replay(seed, round_no):
     """The batch of round `round_no` of seed `seed` (no GPU needed)."""
     global rng
@@ -76,7 +95,7 @@ if __name__ == "__main__":
     rounds = 0
     total = 0
     while time.time() < t_end:
-        docs, bos, eos = gen_batch()
+        docs, bos, eos = gen_corpus_batch() if os.environ.get("SOAK_MODE") == "corpora" else gen_batch()
         text, off = capi.pack_docs(docs)
         got_tok, got_off = ctx.encode_batch(text, off, bos, eos)
         exp_tok, exp_off = orc.encode_batch(text, off, bos, eos, threads=16)
