@@ -90,7 +90,12 @@ if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    ctx, orc = capi.Context(0), Oracle()
+    if os.environ.get("SOAK_VOCAB"):   # a truncated vocabulary (custom data files) on both sides
+        from tests.custom_vocab import truncated_vocabulary
+        v, m, _ = truncated_vocabulary(int(os.environ["SOAK_VOCAB"]))
+        ctx, orc = capi.Context(0, v, m), Oracle(v, m)
+    else:
+        ctx, orc = capi.Context(0), Oracle()
     t_end = time.time() + budget
     rounds = 0
     total = 0
