@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- Llama-3 batch encode throughput on MI355X (BASELINE.json metric, config C2).
+"""bench.py -- Llama-3 batch encode throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c2|c5]
 
-One process per GPU (N > 1: launched by torch.distributed.run).  A step = one l3_encode_batch_device
-call over the rank's shard: 65,536 synthetic English documents of 1,024 B (64 MiB), already resident in
-HBM, token ids and per-document offsets left in HBM.  Documents are independent, so ranks share nothing
-on the data path (weak scaling: every rank owns its own 64 MiB shard); the only collective is the
-all-gather of per-shard {tokens, documents} counts over RCCL once per batch (after the timed steps).
+One process per GPU.  Started plainly with --gpus N > 1 it launches N fresh ranks itself (torch.distributed.run on
+127.0.0.1) BEFORE touching a GPU and forwards rank 0's line; started under torch.distributed.run it is one of the ranks.
 
-Prints ONE JSON line on rank 0 with the whole-job tokens/s, the HBM-roofline figures of the dominant
-kernel (measured live with HIP events on the launch stream) and a CPU baseline (the C restatement of the
-reference's algorithm, threads stated) on a bounded sample of the same workload.
+Workload: the C5 corpus of SURVEY.md 8(d) -- 67,108,864 synthetic English documents of 1,024 B, document i generated from
+seed + i ON the GPU that owns it (tools/l3_corpus_dev.hip; the same bytes as the host generator) -- cut into batches of
+65,536 documents (64 MiB = the C2 configuration of BASELINE.json).  A step = one l3_encode_batch_device call over one
+batch: text resident in HBM, token ids and per-document offsets left in HBM; every step encodes a DIFFERENT batch.
+
+  --config c2 (default)  K steps per rank: rank r's step s is batch s * N + r of the corpus.  Weak scaling (per-GPU work
+                         is fixed as N grows).  This is the headline line: `value` = tokens of all ranks / max time.
+  --config c5            the WHOLE 64 GiB corpus, strong scaling: rank r encodes the contiguous 1,024 / N batches it owns
+                         (--steps is ignored, K = 1,024 / N; --c5-batches shrinks the corpus for rehearsals).
+
+Ranks share nothing on the data path (documents are independent); the only collective is the all-gather of per-rank
+{tokens, documents} over RCCL after the timed steps, from which global token offsets follow.
+
+Rank 0 prints ONE JSON line: whole-job tokens/s, the HBM-roofline figures (kernel times from HIP events recorded on the
+launch stream between the kernels of the timed steps), C3 / C4 as `other_configs` (N = 1 runs only) and a CPU baseline
+(the C restatement of the reference's algorithm on the host cores, threads stated) on a bounded sample of the workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,64 +35,158 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
-DOCS_PER_GPU = 65536
+BATCH_DOCS = 65536
 DOC_BYTES = 1024
+C5_DOCS = 67108864     # 64 GiB
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--docs", type=int, default=DOCS_PER_GPU, help="documents per GPU (default: the C2 config)")
+    ap.add_argument("--config", choices=("c2", "c5"), default="c2")
+    ap.add_argument("--docs", type=int, default=BATCH_DOCS, help="documents per batch (default: the C2 batch)")
+    ap.add_argument("--c5-batches", type=int, default=C5_DOCS // BATCH_DOCS, help="batches of the whole C5 corpus (default 1,024 = 64 GiB)")
     ap.add_argument("--cpu-sample-docs", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="all ranks on GPU 0 with gloo collectives: exercises the N > 1 code path on a one-GPU box (not a measurement)")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start N fresh ranks as CHILD processes (this process has not touched the GPU and
+    never will), forward their output, exit with their code."""
+    port = args.master_port or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "16")
+    return subprocess.call(cmd, env=env)
+
+
+def source_digest():
+    """Digest of the kernel sources: a PMC summary under profiles/ is only quoted if it was taken from these sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tokenizer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def b_alg(n_bytes, n_tok, n_docs):
+    """algorithmic bytes of one launch: input read once + int32 ids written once + uint64 offsets written once"""
+    return n_bytes + 4 * n_tok + 8 * (n_docs + 1)
+
+
+def time_resident(ctx, torch, capi, text, off, steps, warmup, flags=3):
+    """Device-resident timing of one batch given as host arrays (other_configs): returns a dict."""
+    import ctypes as C
+    import numpy as np
+    n_bytes, n_docs = int(text.size), int(off.size - 1)
+    d_text = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    cap = n_bytes * 3 + 2 * n_docs + 16
+    d_out = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_out_off = torch.empty(n_docs + 1, dtype=torch.int64, device="cuda")
+    n_out = C.c_uint64(0)
+    args = (ctx.h, C.c_void_p(d_text.data_ptr()), C.c_uint64(n_bytes), C.c_void_p(d_off.data_ptr()), C.c_uint64(n_docs),
+            C.c_uint32(flags), C.c_void_p(d_out.data_ptr()), C.c_uint64(cap), C.c_void_p(d_out_off.data_ptr()), C.byref(n_out), None)
+    for _ in range(warmup):
+        rc = ctx.lib.l3_encode_batch_device(*args)
+        assert rc == capi.L3_OK, rc
+    torch.cuda.synchronize()
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rc = ctx.lib.l3_encode_batch_device(*args)
+        assert rc == capi.L3_OK, rc
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern, n_prof = ctx.timing_totals()
+    ctx.set_profiling(False)
+    for k in kern:
+        kern[k] /= max(n_prof, 1)
+    n_tok = int(n_out.value)
+    ba = b_alg(n_bytes, n_tok, n_docs)
+    return {"ms": dt * 1e3, "kernels_ms": kern["total"], "tokens": n_tok, "input_bytes": n_bytes, "docs": n_docs, "B_alg": ba,
+            "frac": ba / (kern["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS if kern["total"] > 0 else None,
+            "tokens_per_s": n_tok / dt, "input_gb_per_s": n_bytes / dt / 1e9, "kernel_ms": kern,
+            "steps": steps, "workspace_retries_last_call": ctx.last_counters()["retries"]}, (d_out, d_out_off)
+
+
+def main():
+    args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (world, args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    device = 0 if args.rehearse_one_gpu else local_rank
+    torch.cuda.set_device(device)
+    coll_dev = "cpu" if args.rehearse_one_gpu else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from tokenizer_amd import capi
     from tools import corpora
+    import ctypes as C
 
-    ctx = capi.Context(device=local_rank)
+    ctx = capi.Context(device=device)
     n_docs = args.docs
-    text, off = corpora.english(n_docs, DOC_BYTES, first_doc=rank * n_docs)
-    n_bytes = int(text.size)
-    d_text = torch.from_numpy(text).cuda()
-    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    n_bytes = n_docs * DOC_BYTES
+    from tokenizer_amd import shard
+    my_batches = shard.corpus_batches(args.config, rank, world, args.steps, args.c5_batches)
+    warm_batches = my_batches[:min(args.warmup, len(my_batches))]
+    scaling = "strong" if args.config == "c5" else "weak"
+    steps = len(my_batches)
+
+    # ---- the rank's slice of the corpus, generated on its GPU and resident before the timed region starts
+    d_text = torch.empty(steps * n_bytes, dtype=torch.uint8, device="cuda")
+    g0 = time.perf_counter()
+    for i, b in enumerate(my_batches):
+        corpora.english_device(d_text[i * n_bytes:(i + 1) * n_bytes], b * n_docs, n_docs, DOC_BYTES)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - g0
+    d_off = torch.arange(n_docs + 1, dtype=torch.int64, device="cuda") * DOC_BYTES   # every batch: 65,536 x 1,024 B
     out_cap = n_bytes // 2 + 2 * n_docs
     d_out = torch.empty(out_cap, dtype=torch.int32, device="cuda")
     d_out_off = torch.empty(n_docs + 1, dtype=torch.int64, device="cuda")
-    counts = torch.zeros(2, dtype=torch.int64, device="cuda")
-    gathered = torch.zeros(2 * world, dtype=torch.int64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
     flags = capi.L3_BOS | capi.L3_EOS
 
     # the call of one step, with its arguments marshalled once: the host side of a step is in the timed region too
-    import ctypes as C
     n_out = C.c_uint64(0)
-    call_args = (ctx.h, C.c_void_p(d_text.data_ptr()), C.c_uint64(n_bytes), C.c_void_p(d_off.data_ptr()), C.c_uint64(n_docs),
-                 C.c_uint32(flags), C.c_void_p(d_out.data_ptr()), C.c_uint64(out_cap), C.c_void_p(d_out_off.data_ptr()),
-                 C.byref(n_out), C.c_void_p(stream))
     encode = ctx.lib.l3_encode_batch_device
+    base_ptr = d_text.data_ptr()
 
-    def step():
-        rc = encode(*call_args)
+    def call_args(i):
+        return (ctx.h, C.c_void_p(base_ptr + i * n_bytes), C.c_uint64(n_bytes), C.c_void_p(d_off.data_ptr()), C.c_uint64(n_docs),
+                C.c_uint32(flags), C.c_void_p(d_out.data_ptr()), C.c_uint64(out_cap), C.c_void_p(d_out_off.data_ptr()),
+                C.byref(n_out), None)
+
+    all_args = [call_args(i) for i in range(steps)]
+
+    def step(i):
+        rc = encode(*all_args[i])
         if rc != capi.L3_OK:
             raise RuntimeError("l3_encode_batch_device failed: %d" % rc)
         return n_out.value
@@ -91,98 +197,135 @@ def main():
         torch.cuda.synchronize()
 
     ctx.set_profiling(True)   # HIP events on the launch stream around every kernel of every call
-    for _ in range(args.warmup):
-        step()
+    for i in range(len(warm_batches)):
+        step(i)
     sync()
     ctx.set_profiling(True)   # resets the library's per-kernel sums: they cover exactly the timed steps
     t0 = time.perf_counter()
-    n_tok = 0
-    for _ in range(args.steps):
-        n_tok = step()
+    n_tok_total = 0
+    for i in range(steps):
+        n_tok_total += step(i)
     sync()
     dt = time.perf_counter() - t0
     kern, n_prof = ctx.timing_totals()
-    if n_prof != args.steps:
-        raise RuntimeError("profiled %d calls, expected %d (a call was retried with a larger workspace?)" % (n_prof, args.steps))
+    ctx.set_profiling(False)
+    if n_prof != steps:
+        raise RuntimeError("profiled %d calls, expected %d (a call was retried with a larger workspace?)" % (n_prof, steps))
     for k in kern:
-        kern[k] /= max(args.steps, 1)
+        kern[k] /= max(steps, 1)
     counters = ctx.last_counters()
+    last_tok = int(n_out.value)
 
-    global_token_base = 0
+    my_docs = steps * n_docs
+    my_bytes = steps * n_bytes
     if dist is not None:
-        # The path has no exchange step: ranks share nothing while they encode.  What a job needs once per batch to
-        # address the shards as one array is each shard's {tokens, documents}: 16 bytes per rank over RCCL, after
-        # the timed steps (the counts of a step are known only when it has finished anyway).
-        counts[0] = n_tok
-        counts[1] = n_docs
-        dist.all_gather_into_tensor(gathered, counts)
-        per_rank = gathered.view(world, 2).cpu()
-        global_token_base = int(per_rank[:rank, 0].sum().item())
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        # The path has no exchange step: ranks share nothing while they encode.  What a job needs to address the shards
+        # as one array is each shard's {tokens, documents}: 16 bytes per rank over RCCL, after the timed steps.
+        global_token_base, global_doc_base, (tot_tok, tot_docs) = shard.gather_counts(dist, n_tok_total, my_docs, device=coll_dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tt = torch.tensor([n_tok, n_bytes], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        tot_tok, tot_bytes = int(tt[0].item()), int(tt[1].item())
+        tot_bytes = tot_docs * DOC_BYTES
+        assert global_token_base <= tot_tok and global_doc_base <= tot_docs
     else:
-        tot_tok, tot_bytes = n_tok, n_bytes
+        tot_tok, tot_bytes, tot_docs = n_tok_total, my_bytes, my_docs
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = tot_tok * args.steps / dt
-        # algorithmic bytes of one launch: input read once + int32 ids written once + uint64 offsets
-        b_alg = n_bytes + 4 * n_tok + 8 * (n_docs + 1)
+        ms_per_step = dt / steps * 1e3
+        value = tot_tok / dt
+        tok_per_batch = n_tok_total / steps
+        ba = b_alg(n_bytes, tok_per_batch, n_docs)
         dom = max(("tile", "merge", "slow", "emit", "scan", "docs"), key=lambda k: kern[k])
-        achieved = b_alg / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
-        pipeline = b_alg / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
+        pipeline = ba / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
+        dom_gbs = ba / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        if args.config == "c5":
+            workload = ("C5: %d synthetic English docs x %d B (%.1f GiB) generated on the owning GPU, sharded by document over %d "
+                        "GPU(s), %d batches of %d docs per GPU encoded back to back, BOS+EOS, inputs and outputs resident in HBM"
+                        % (tot_docs, DOC_BYTES, tot_bytes / 2 ** 30, world, steps, n_docs))
+        else:
+            workload = ("C2: %d synthetic English docs x %d B per batch (64 MiB), one batch per step and GPU, every step a different "
+                        "batch of the C5 corpus generated on the GPU, BOS+EOS, inputs and outputs resident in HBM" % (n_docs, DOC_BYTES))
         result = {
             "metric": "encode tokens/sec (whole node), Llama-3 BPE", "value": value, "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-            "config": {"workload": "C2: %d synthetic English docs x %d B per GPU, batched encode, BOS+EOS, inputs and "
-                                   "outputs resident in HBM" % (n_docs, DOC_BYTES),
-                       "docs_per_gpu": n_docs, "doc_bytes": DOC_BYTES, "parallelism": "dp%d (documents sharded, no data-path collective)" % world},
-            "input_gb_per_s": tot_bytes * args.steps / dt / 1e9,
-            "tokens_per_step": tot_tok, "bytes_per_token": tot_bytes / max(tot_tok - 2 * n_docs * world, 1),
-            "kernel_ms": kern, "deferred_pretokens": {"short": counters["short_pretokens"], "slow": counters["slow_pretokens"]},
-            "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": b_alg, "kernel_avg_ms": kern[dom],
-                         "pipeline_achieved": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBS},
+            "n_gpus": world, "steps": steps, "warmup": len(warm_batches), "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "config": {"workload": workload, "config": args.config, "docs_per_batch": n_docs, "doc_bytes": DOC_BYTES,
+                       "batches_per_gpu": steps, "corpus_bytes": tot_bytes,
+                       "parallelism": "dp%d (documents sharded, no data-path collective)" % world,
+                       **({"rehearsal": "all ranks share GPU 0, gloo collectives: NOT a measurement"} if args.rehearse_one_gpu else {})},
+            "input_gb_per_s": tot_bytes / dt / 1e9,
+            "tokens_total": tot_tok, "tokens_per_batch": tok_per_batch,
+            "bytes_per_token": my_bytes / max(n_tok_total - 2 * my_docs, 1),
+            "corpus_generation_s": gen_s,
+            "kernel_ms": kern, "deferred_pretokens_last_batch": {"short": counters["short_pretokens"], "slow": counters["slow_pretokens"]},
+            # frac: algorithmic bytes / (first kernel start -> last kernel end) / peak, as SURVEY 8(d) defines it
+            "roofline": {"bound": "hbm", "achieved": pipeline, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pipeline / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": ba, "kernels_ms_per_launch": kern["total"],
+                         "wall_frac": ba / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "dominant": {"kernel": dom + "_kernel", "avg_ms": kern[dom], "achieved": dom_gbs, "frac": dom_gbs / HBM_PEAK_GBS}},
         }
-        # HBM traffic of the dominant kernel: not measurable from inside this process; taken from the committed
-        # rocprofv3 PMC passes of this same command (profiles/*_pmc_hbm_summary.json, see profiles/README.md)
+        # HBM traffic per launch (all kernels of the pipeline) from the committed rocprofv3 PMC passes of this command --
+        # quoted only when that summary was taken from exactly these kernel sources
         try:
             import glob
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_summary.json")))[-1]
-            kinfo = json.load(open(pm))["kernels"][dom + "_kernel"]
-            result["roofline"]["traffic"] = kinfo["hbm_bytes_per_launch_corrected"]
-            result["roofline"]["traffic_source"] = os.path.relpath(pm, ROOT)
+            summ = json.load(open(pm))
+            if summ.get("source_digest") == source_digest():
+                result["roofline"]["traffic"] = sum(k["hbm_bytes_per_launch_corrected"] for k in summ["kernels"].values())
+                result["roofline"]["traffic_source"] = os.path.relpath(pm, ROOT)
+                result["roofline"]["dominant"]["traffic"] = summ["kernels"].get(dom + "_kernel", {}).get("hbm_bytes_per_launch_corrected")
+            else:
+                result["roofline"]["traffic_source"] = "none: %s was taken from other kernel sources" % os.path.relpath(pm, ROOT)
         except Exception:
             pass
+
+        if world == 1 and not args.no_other_configs:
+            other = {}
+            try:
+                # C3: 16 multilingual documents of 4 MiB (CJK runs of up to 4,096 characters, Cyrillic, emoji)
+                text3, off3 = corpora.multilingual(16, 4 << 20)
+                other["c3_16x4MiB"], _ = time_resident(ctx, torch, capi, text3, off3, steps=5, warmup=2)
+                # C4: the pathological documents as ONE batch (1 MiB each: one blank / tab / letter repeated, digits,
+                # newline patterns, random and invalid bytes, special tokens and near misses)
+                docs4 = corpora.pathological(1 << 20)
+                text4, off4 = capi.pack_docs(docs4)
+                other["c4_batch"], _ = time_resident(ctx, torch, capi, text4, off4, steps=3, warmup=1)
+                for name, d in (("c4_1MiB_one_letter", b"a" * (1 << 20)), ("c4_1MiB_invalid_bytes", b"\xff" * (1 << 20))):
+                    t, o = capi.pack_docs([d])
+                    other[name], _ = time_resident(ctx, torch, capi, t, o, steps=3, warmup=1)
+            except Exception as e:   # the headline must not die with a side measurement
+                other["error"] = repr(e)
+            result["other_configs"] = other
+
         if not args.no_cpu_baseline:
             from tests.oracle import Oracle
             threads = min(16, os.cpu_count() or 1)
             ns = min(args.cpu_sample_docs, n_docs)
             oracle = Oracle()
-            s_text, s_off = text[:ns * DOC_BYTES], off[:ns + 1]
-            passes = 24  # about 30 core-seconds of CPU work on 16 threads
+            # the first batch of this rank, from the HOST generator (the same bytes the GPU generated: checked)
+            s_text, s_off = corpora.english(ns, DOC_BYTES, first_doc=my_batches[0] * n_docs)
+            same_bytes = bool(np.array_equal(d_text[:ns * DOC_BYTES].cpu().numpy(), s_text))
+            passes = 12  # about 15 core-seconds x 16 threads
             c0 = time.perf_counter()
             for _ in range(passes):  # one tokenizer, its pre-token caches persist as the reference's default cache does
                 exp_tok, exp_off = oracle.encode_batch(s_text, s_off, True, True, threads=threads)
             cdt = time.perf_counter() - c0
+            step(0)
+            torch.cuda.synchronize()
             got_off = d_out_off[:ns + 1].cpu().numpy().astype(np.uint64)
             got_tok = d_out[:int(got_off[-1])].cpu().numpy()
-            parity = bool(np.array_equal(got_off, exp_off) and np.array_equal(got_tok, exp_tok))
+            parity = bool(same_bytes and np.array_equal(got_off, exp_off) and np.array_equal(got_tok, exp_tok))
             result["cpu_baseline"] = {"value": passes * exp_tok.size / cdt, "unit": "tokens/s", "cores": threads, "kind": "port",
-                                      "sample": "%d passes over the first %d documents (%d MiB) of the same C2 shard; C restatement "
+                                      "sample": "%d passes over the first %d documents (%d MiB) of rank 0's first batch; C restatement "
                                                 "of the reference algorithm, document-per-thread work queue, per-thread "
                                                 "pre-token caches kept across passes" % (passes, ns, ns * DOC_BYTES >> 20),
                                       "seconds": cdt, "core_seconds": cdt * threads, "input_gb_per_s": passes * ns * DOC_BYTES / cdt / 1e9}
             result["parity_vs_oracle_on_sample"] = parity
+            result["device_corpus_equals_host_corpus_on_sample"] = same_bytes
             if not parity:
                 result["error"] = "GPU output differs from the oracle on the CPU-baseline sample"
-        print(json.dumps(result))
+        del last_tok
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -26,6 +26,7 @@ typedef struct l3_ctx l3_ctx;
 #define L3_E_OUTPUT_CAP (-4)  /* output buffer too small; *n_tok / *n_bytes holds the size needed */
 #define L3_E_NO_DEVICE (-5)   /* no usable gfx950 device */
 #define L3_E_NOT_FOUND (-6)   /* reference: ErrTokenNotFound / ErrInvalidToken (tokenizer.go:357-368) */
+#define L3_E_SCRATCH (-7)     /* l3_encode_batch_device_noalloc: the batch needs more workspace than the static array holds */
 
 /* EncodeOptions{BOS, EOS} (tokenizer.go:107-112); nil options == L3_BOS|L3_EOS (tokenizer.go:218-220) */
 #define L3_BOS 1u
@@ -58,6 +59,22 @@ int l3_encode_batch(l3_ctx* ctx, const uint8_t* text, const uint64_t* doc_off, u
 int l3_encode_batch_device(l3_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off,
                            uint64_t n_docs, uint32_t flags, int32_t* d_out_tok, uint64_t out_cap,
                            uint64_t* d_out_off, uint64_t* n_tok, void* stream);
+
+/* l3_encode_batch_device for callers that must not allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * arguments, results and error codes as l3_encode_batch_device, but its workspace (intermediate items, deferred pre-token
+ * lists, counters) is a file-scope __device__ array of L3_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds
+ * until the process ends; the call itself performs no hipMalloc / hipFree / allocating library call.
+ * Limits: n_bytes <= L3_NOALLOC_MAX_BYTES and n_docs <= L3_NOALLOC_MAX_DOCS, else L3_E_INVALID_ARG; a batch within those
+ * limits whose deferred pre-tokens outgrow the fixed lists (pathological text) returns L3_E_SCRATCH -- use
+ * l3_encode_batch_device for it.  All calls on one GPU share the array, whatever the context: the library serialises them
+ * inside one process; two PROCESSES each have their own copy. */
+#define L3_NOALLOC_MAX_BYTES (4u << 20)
+#define L3_NOALLOC_MAX_DOCS 65536u
+#define L3_NOALLOC_SCRATCH_BYTES (40u << 20)
+int l3_encode_batch_device_noalloc(l3_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off,
+                                   uint64_t n_docs, uint32_t flags, int32_t* d_out_tok, uint64_t out_cap,
+                                   uint64_t* d_out_off, uint64_t* n_tok, void* stream);
 
 /* Pre-token boundaries: kinds[i] = 1 if a pre-token starts at byte i, 2 if a special token starts there, else 0.
  * flags = L3_NO_SPECIAL: Tokenizer.PreTokenize (tokenizer.go:490-506 -> pretokenizer.Tokenize), which knows no

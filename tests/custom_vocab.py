@@ -17,8 +17,10 @@ import numpy as np
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tokenizer_amd", "data")
 
 
-def truncated_vocabulary(n_tokens):
-    """Returns (vocab_file_bytes, merges_file_bytes, n_merges_kept)."""
+def truncated_vocabulary(n_tokens, full_merges=False):
+    """Returns (vocab_file_bytes, merges_file_bytes, n_merges_kept).  full_merges: the shipped merges file unchanged (the
+    reference loads that too: pairs naming unknown ids are skipped, decoder.go:61-63, and a rule whose product is not in the
+    vocabulary produces nothing, bpe.go:157-161)."""
     vraw = base64.b64decode(open(os.path.join(DATA, "vocab_base64.txt"), "rb").read())
     mraw = base64.b64decode(open(os.path.join(DATA, "merges_binary.txt"), "rb").read())
     toks = [t for t in vraw.split(b"\n") if t]
@@ -27,6 +29,9 @@ def truncated_vocabulary(n_tokens):
     n_ids = bits.size // 17
     w = (1 << np.arange(16, -1, -1)).astype(np.int64)
     ids = bits[:n_ids * 17].reshape(n_ids, 17).astype(np.int64) @ w
+    if full_merges:
+        return (base64.b64encode(b"\n".join(toks[:n_tokens]) + b"\n"), open(os.path.join(DATA, "merges_binary.txt"), "rb").read(),
+                n_ids // 2)
     index = {t: i for i, t in enumerate(toks)}
     kept = []
     for k in range(0, n_ids - 1, 2):

@@ -30,7 +30,23 @@ def test_create_rejects_bad_data_without_gpu():
     assert b"vocabulary" in lib.l3_last_error(None)
     vocab, merges = capi.read_data_files()
     import base64
-    bad = base64.b64encode(b"\xff" * 34)   # pairs of id 131071: not in the vocabulary (a shorter merge list would be valid data)
+
+    import numpy as np
+
+    def pack(pairs):   # 17 bits per id, most significant bit first (decoder.go:75-126)
+        ids = np.asarray(pairs, dtype=np.int64).reshape(-1)
+        bits = ((ids[:, None] >> np.arange(16, -1, -1)) & 1).astype(np.uint8).reshape(-1)
+        return base64.b64encode(np.packbits(bits).tobytes())
+
+    # rules out of rank order (products must not decrease: 'in' = 258 before the rule of token 256)
+    bad = pack([(72, 77), (220, 220)])
     rc = lib.l3_create(vocab, len(vocab), bad, len(bad), 0, C.byref(h))
     assert rc == capi.L3_E_DATA and not h.value
-    assert b"unknown token id" in lib.l3_last_error(None)
+    assert b"ascending product id" in lib.l3_last_error(None)
+    # pairs naming ids beyond the token list are skipped as the reference does (decoder.go:61-63): valid data, so the
+    # call gets as far as looking for a GPU
+    skipped = base64.b64encode(b"\xff" * 34)
+    rc = lib.l3_create(vocab, len(vocab), skipped, len(skipped), 0, C.byref(h))
+    assert rc in (capi.L3_E_NO_DEVICE, capi.L3_OK)
+    if rc == capi.L3_OK:
+        lib.l3_destroy(h)

@@ -68,6 +68,25 @@ def test_host_table_builder_on_custom_files(files, small_oracle):
         assert got == small_oracle.bpe_raw(w), w[:20]
 
 
+def test_truncated_vocabulary_with_the_full_merges_file(files, small_oracle):
+    """What the reference loads, this loads: the shipped merges file beside a truncated vocabulary.  Pairs that name ids
+    beyond the token list are skipped (decoder.go:61-63); rules whose product is missing rank after every productive rule
+    and change no output (bpe.go:157-161), so the tokenizer equals the one built from the filtered merges."""
+    from tests.hostshim import HostShim
+    from tests.oracle import Oracle
+    v, m_full, _ = truncated_vocabulary(N_BASE, full_merges=True)
+    assert v == files[0]
+    o_full = Oracle(v, m_full)
+    h = HostShim(v, m_full)
+    assert h.stats()["n_tokens"] == N_BASE + 256
+    rng = random.Random(12)
+    words = [corpus.random_word(rng) for _ in range(3000)] + [b"a" * 300, "中文".encode() * 40, b" " * 90, bytes(range(33, 127)) * 2]
+    for w in words:
+        exp = o_full.bpe_raw(w)
+        assert exp == small_oracle.bpe_raw(w), w[:20]      # the reference's behaviour on the full file == the filtered file
+        assert h.bpe(w) == exp, w[:20]
+
+
 @pytest.fixture(scope="module")
 def small_ctx(files):
     from tokenizer_amd import capi

@@ -360,6 +360,44 @@ def test_device_pointer_api(ctx, oracle):
     assert rc == capi.L3_E_OUTPUT_CAP and need == exp_tok.size
 
 
+def test_caller_stream_may_be_destroyed_between_calls(oracle):
+    """The library keeps nothing of the caller's after a call -- not the stream either: encode on stream A, destroy A,
+    encode on the context's own stream and on a new stream B."""
+    import torch
+    from tokenizer_amd import capi
+    c = capi.Context(device=0)
+    try:
+        text, off = corpora.english(256, 1024)
+        exp_tok, exp_off = oracle.encode_batch(text, off, True, True, threads=8)
+        d_text = torch.from_numpy(text).cuda()
+        d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+        cap = text.size // 2
+        d_out = torch.empty(cap, dtype=torch.int32, device="cuda")
+        d_out_off = torch.empty(off.size, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+
+        def run(stream_handle):
+            d_out.fill_(-1)
+            torch.cuda.synchronize()
+            rc, n = c.encode_batch_device(d_text.data_ptr(), text.size, d_off.data_ptr(), off.size - 1, 3, d_out.data_ptr(), cap,
+                                          d_out_off.data_ptr(), stream_handle)
+            assert rc == capi.L3_OK, c._err(rc)
+            assert n == exp_tok.size and np.array_equal(d_out[:n].cpu().numpy(), exp_tok)
+
+        a = torch.cuda.Stream()
+        run(a.cuda_stream)
+        del a                      # torch destroys the stream
+        import gc
+        gc.collect()
+        run(None)                  # the context's own stream
+        b = torch.cuda.Stream()
+        run(b.cuda_stream)
+        run(b.cuda_stream)
+        run(None)
+    finally:
+        c.close()
+
+
 def test_decode_round_trip(ctx, oracle):
     rng = random.Random(11)
     docs = [corpus.random_doc(rng, special_rate=0.0) for _ in range(2000)]

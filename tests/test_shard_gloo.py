@@ -70,3 +70,14 @@ def test_partition_is_balanced_and_total():
         sizes = [int(off[b] - off[a]) for a, b in zip(cuts, cuts[1:])]
         assert max(sizes) - min(sizes) <= 2 * 5000
     assert shard.partition_by_bytes(np.array([0], dtype=np.uint64), 4) == [0, 0, 0, 0, 0]
+
+
+def test_corpus_batches_are_disjoint_and_cover():
+    from tokenizer_amd import shard
+    for world in (1, 2, 3, 4, 8):
+        got = [shard.corpus_batches("c5", r, world, 0, 1024) for r in range(world)]
+        flat = [b for g in got for b in g]
+        assert flat == list(range(1024))                                 # contiguous, in rank order, nothing twice
+        assert max(map(len, got)) - min(map(len, got)) <= 1
+        got = [shard.corpus_batches("c2", r, world, 20, 1024) for r in range(world)]
+        assert sorted(b for g in got for b in g) == list(range(20 * world)) and all(len(g) == 20 for g in got)

@@ -19,6 +19,9 @@ L3_E_HIP = -3
 L3_E_OUTPUT_CAP = -4
 L3_E_NO_DEVICE = -5
 L3_E_NOT_FOUND = -6
+L3_E_SCRATCH = -7
+L3_NOALLOC_MAX_BYTES = 4 << 20
+L3_NOALLOC_MAX_DOCS = 65536
 L3_BOS = 1
 L3_EOS = 2
 L3_NO_SPECIAL = 4
@@ -32,6 +35,8 @@ SYMBOLS = [
     ("l3_encode_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     ("l3_encode_batch_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P,
                                         C.POINTER(C.c_uint64), _P]),
+    ("l3_encode_batch_device_noalloc", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P,
+                                                C.POINTER(C.c_uint64), _P]),
     ("l3_pretokenize_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P]),
     ("l3_host_alloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     ("l3_host_free", C.c_int, [_P, _P]),
@@ -181,11 +186,12 @@ class Context:
 
     # ---- device-pointer API (torch tensors are only a way to hold HBM here) --------------------------
     def encode_batch_device(self, d_text_ptr, n_bytes, d_off_ptr, n_docs, flags, d_out_ptr, out_cap, d_out_off_ptr,
-                            stream=None):
-        """Raw device pointers (ints).  Returns (rc, n_tok)."""
+                            stream=None, noalloc=False):
+        """Raw device pointers (ints).  Returns (rc, n_tok).  noalloc: the entry point whose workspace is the
+        library's static device array (l3_encode_batch_device_noalloc)."""
         n = C.c_uint64(0)
-        rc = self.lib.l3_encode_batch_device(self.h, d_text_ptr, n_bytes, d_off_ptr, n_docs, flags, d_out_ptr, out_cap,
-                                             d_out_off_ptr, C.byref(n), stream)
+        fn = self.lib.l3_encode_batch_device_noalloc if noalloc else self.lib.l3_encode_batch_device
+        rc = fn(self.h, d_text_ptr, n_bytes, d_off_ptr, n_docs, flags, d_out_ptr, out_cap, d_out_off_ptr, C.byref(n), stream)
         return rc, int(n.value)
 
     # ---- small queries ------------------------------------------------------------------------------

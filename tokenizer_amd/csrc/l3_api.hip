@@ -19,6 +19,35 @@ namespace {
 
 thread_local std::string g_create_err;
 
+// ---- the workspace of l3_encode_batch_device_noalloc (include/l3hip.h) ---------------------------------------------
+// A file-scope device array: every GPU the library runs on holds its own copy, at its own address, until the process
+// ends.  In host code the NAME of the array is only a handle for hipGetSymbolAddress; kernels, memsets and copies get the
+// per-device address that call returned (g_scratch[device].ptr), never the name.
+constexpr size_t kNoAllocScratchBytes = (size_t)L3_NOALLOC_SCRATCH_BYTES;
+static __device__ __attribute__((used)) __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+constexpr int kMaxDevices = 64;
+struct DeviceScratch {
+    unsigned char* ptr = nullptr;   // device address of `scratch` on this GPU
+    std::mutex mu;                  // calls on one GPU share the array: one at a time
+};
+DeviceScratch g_scratch[kMaxDevices];
+std::mutex g_scratch_mu;
+
+// With `device` current: the address of this GPU's copy of the array (asked once per device).
+hipError_t scratch_address(int device, unsigned char** out) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_scratch[device].ptr) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch[device].ptr = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch[device].ptr;
+    return hipSuccess;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -36,6 +65,9 @@ struct DevBuf {
     template <class U> U* as() const { return reinterpret_cast<U*>(p); }
 };
 
+// Capacities of the lists a call appends to (entries, not bytes; scratch_cap in bytes).
+struct Caps { uint64_t slow_cap, miss_shard_cap, mpool_shard_cap, pool_cap, scratch_cap; };
+
 }  // namespace
 
 struct l3_ctx {
@@ -43,11 +75,16 @@ struct l3_ctx {
     HostTables H;
     Tables T{};
     DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes;
-    bool clear_pending = false;       // a clear of w_status is queued on clear_stream
-    hipStream_t clear_stream = nullptr;
-    DevBuf w_stream, w_items, w_extra, w_base, w_pre, w_flag, w_doc0, w_docitem, w_slow, w_miss, w_missres, w_pool, w_scratch, w_status;
+    // The status word is cleared AFTER a call has read it back (so the clear runs between two calls, not in front of the
+    // kernels).  The clear is ordered before the next call's kernels by an event the context owns: the caller's stream
+    // handle is never kept, it may be destroyed between two calls.
+    bool clear_pending = false;       // a clear of w_status has been queued and ev_clear recorded behind it
+    bool clear_on_own = false;        // ... on the context's own stream (same-stream order makes the wait unnecessary)
+    hipEvent_t ev_clear = nullptr;
+    DevBuf w_arena, w_status;         // the per-call workspace (one block, carve_workspace) and the status word
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
-    uint64_t slow_cap = 0, miss_shard_cap = 0, mpool_shard_cap = 0, pool_cap = 0, scratch_cap = 0;
+    Caps caps{0, 0, 0, 0, 0};         // list capacities inside the workspace, grow-only
+    unsigned char* na_scratch = nullptr;  // this GPU's copy of the file-scope array `scratch` (hipGetSymbolAddress at l3_create)
     Status* h_status = nullptr;          // pinned
     unsigned long long* h_total = nullptr;  // pinned
     hipStream_t stream = nullptr;
@@ -113,56 +150,100 @@ int upload_tables(l3_ctx* c) {
     return L3_OK;
 }
 
-int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W) {
+// Lays the per-call workspace of a batch of n_bytes / n_docs out in one block of memory starting at `base` (256-byte
+// aligned pieces, in a fixed order) and returns the bytes it takes.  base == nullptr: only the size.  The status word is
+// not part of the block (the context keeps it across calls); `status` is stored as given.
+size_t carve_workspace(uint8_t* base, uint64_t n_bytes, uint64_t n_docs, const Caps& K, Status* status, Workspace& W) {
     const uint64_t n_tiles = num_tiles(n_bytes);
-    HIPCHK(c, c->w_stream.ensure(n_tiles * kTileCap * sizeof(int32_t)));
-    HIPCHK(c, c->w_items.ensure(n_tiles * 4));
-    HIPCHK(c, c->w_extra.ensure(n_tiles * 8));  // tile_extra + tile_digits
-    HIPCHK(c, c->w_base.ensure((n_tiles / 1024 + 2) * 8));
-    HIPCHK(c, c->w_pre.ensure(n_tiles * sizeof(TileRec)));
-    HIPCHK(c, c->w_flag.ensure(n_tiles * 4));
-    HIPCHK(c, c->w_doc0.ensure((n_tiles + 1) * 4));
-    HIPCHK(c, c->w_docitem.ensure((n_docs + 1) * 4));
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        uint8_t* p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    W.stream = reinterpret_cast<int32_t*>(take(n_tiles * kTileCap * sizeof(int32_t)));
+    W.tile_items = reinterpret_cast<uint32_t*>(take(n_tiles * 4));
+    W.tile_extra = reinterpret_cast<uint32_t*>(take(n_tiles * 8));  // tile_extra + tile_digits
+    W.tile_digits = base ? W.tile_extra + n_tiles : nullptr;
+    W.tile_base = reinterpret_cast<uint64_t*>(take((n_tiles / 1024 + 2) * 8));
+    W.tile_rec = reinterpret_cast<TileRec*>(take(n_tiles * sizeof(TileRec)));
+    W.tile_flag = reinterpret_cast<uint32_t*>(take(n_tiles * 4));
+    W.tile_doc0 = reinterpret_cast<uint32_t*>(take((n_tiles + 1) * 4));
+    W.doc_item = reinterpret_cast<uint32_t*>(take((n_docs + 1) * 4));
+    W.slow = reinterpret_cast<SlowEntry*>(take(K.slow_cap * sizeof(SlowEntry)));
+    W.miss_in = reinterpret_cast<MissIn*>(take(K.miss_shard_cap * kMissShards * sizeof(MissIn)));
+    W.miss_res = reinterpret_cast<uint64_t*>(take(K.miss_shard_cap * kMissShards * sizeof(uint64_t)));
+    W.pool = reinterpret_cast<int32_t*>(take((K.mpool_shard_cap * kMissShards + K.pool_cap) * sizeof(int32_t)));
+    W.scratch = take(K.scratch_cap);
+    W.status = status;
+    W.slow_cap = K.slow_cap;
+    W.miss_shard_cap = K.miss_shard_cap;
+    W.mpool_shard_cap = K.mpool_shard_cap;
+    W.pool_cap = K.pool_cap;
+    W.scratch_cap = K.scratch_cap;
+    return off;
+}
+
+// smallest list capacities a batch of n_bytes starts with (they grow from the status word of an overflowing attempt)
+Caps initial_caps(uint64_t n_bytes) {
+    Caps K;
+    K.slow_cap = n_bytes / 256 + 1024;
+    K.miss_shard_cap = n_bytes / 2048 + 256;
+    K.pool_cap = n_bytes / 8 + 4096;
+    K.mpool_shard_cap = n_bytes / 16 / kMissShards + 1024;
+    K.scratch_cap = 16ull << 20;
+    return K;
+}
+
+// A stream placeholder is -2 - e with e < 2^31 - 2: short entries use e = shard * miss_shard_cap + index < kSlowBase,
+// slow entries e = kSlowBase + index.  Lists that outgrow that space (tens of GiB of text in one call, or lists grown by
+// many overflow retries) cannot be addressed: the caller has to split the batch.
+bool caps_addressable(const Caps& K) {
+    return (uint64_t)kMissShards * K.miss_shard_cap < (uint64_t)kSlowBase && K.slow_cap < (uint64_t)kSlowBase - 2;
+}
+
+int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W) {
     if (!c->w_status.p) {
         HIPCHK(c, c->w_status.ensure(sizeof(Status)));
         HIPCHK(c, hipMemset(c->w_status.p, 0, sizeof(Status)));
     }
-    uint64_t slow_min = n_bytes / 256 + 1024, miss_min = n_bytes / 2048 + 256, pool_min = n_bytes / 8 + 4096,
-             scratch_min = 16ull << 20;
-    if (c->slow_cap < slow_min) c->slow_cap = slow_min;
-    if (c->miss_shard_cap < miss_min) c->miss_shard_cap = miss_min;
-    if (c->pool_cap < pool_min) c->pool_cap = pool_min;
-    const uint64_t mpool_min = n_bytes / 16 / kMissShards + 1024;
-    if (c->mpool_shard_cap < mpool_min) c->mpool_shard_cap = mpool_min;
-    if (c->scratch_cap < scratch_min) c->scratch_cap = scratch_min;
-    HIPCHK(c, c->w_slow.ensure(c->slow_cap * sizeof(SlowEntry)));
-    HIPCHK(c, c->w_miss.ensure(c->miss_shard_cap * kMissShards * sizeof(MissIn)));
-    HIPCHK(c, c->w_missres.ensure(c->miss_shard_cap * kMissShards * sizeof(uint64_t)));
-    HIPCHK(c, c->w_pool.ensure((c->mpool_shard_cap * kMissShards + c->pool_cap) * sizeof(int32_t)));
-    HIPCHK(c, c->w_scratch.ensure(c->scratch_cap));
-    W.stream = c->w_stream.as<int32_t>();
-    W.tile_items = c->w_items.as<uint32_t>();
-    W.tile_extra = c->w_extra.as<uint32_t>();
-    W.tile_digits = W.tile_extra + n_tiles;
-    W.tile_base = c->w_base.as<uint64_t>();
-    W.tile_rec = c->w_pre.as<TileRec>();
-    W.tile_flag = c->w_flag.as<uint32_t>();
-    W.tile_doc0 = c->w_doc0.as<uint32_t>();
-    W.doc_item = c->w_docitem.as<uint32_t>();
-    W.slow = c->w_slow.as<SlowEntry>();
-    W.miss_in = c->w_miss.as<MissIn>();
-    W.miss_res = c->w_missres.as<uint64_t>();
-    W.miss_shard_cap = c->miss_shard_cap;
-    W.pool = c->w_pool.as<int32_t>();
-    W.scratch = c->w_scratch.as<uint8_t>();
-    W.status = c->w_status.as<Status>();
-    W.slow_cap = c->slow_cap;
-    W.pool_cap = c->pool_cap;
-    W.mpool_shard_cap = c->mpool_shard_cap;
-    W.scratch_cap = c->scratch_cap;
+    const Caps K0 = initial_caps(n_bytes);
+    Caps& K = c->caps;   // grow-only across calls
+    if (K.slow_cap < K0.slow_cap) K.slow_cap = K0.slow_cap;
+    if (K.miss_shard_cap < K0.miss_shard_cap) K.miss_shard_cap = K0.miss_shard_cap;
+    if (K.pool_cap < K0.pool_cap) K.pool_cap = K0.pool_cap;
+    if (K.mpool_shard_cap < K0.mpool_shard_cap) K.mpool_shard_cap = K0.mpool_shard_cap;
+    if (K.scratch_cap < K0.scratch_cap) K.scratch_cap = K0.scratch_cap;
+    if (!caps_addressable(K)) {
+        c->err = "batch too large for one call (deferred pre-token lists exceed 2^30 entries): split it";
+        return L3_E_INVALID_ARG;
+    }
+    const size_t need = carve_workspace(nullptr, n_bytes, n_docs, K, nullptr, W);
+    HIPCHK(c, c->w_arena.ensure(need));
+    carve_workspace(c->w_arena.as<uint8_t>(), n_bytes, n_docs, K, c->w_status.as<Status>(), W);
     W.bos_id = c->H.special_id[0];  // canonical index 0 / 1 = <|begin_of_text|> / <|end_of_text|> (l3_tables.cpp)
     W.eos_id = c->H.special_id[1];
     return L3_OK;
+}
+
+// Queues the clear of the status word behind everything on `stream` and records the context's event behind it.
+int queue_status_clear(l3_ctx* c, const Workspace& W, hipStream_t stream) {
+    HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream));
+    HIPCHK(c, hipEventRecord(c->ev_clear, stream));
+    c->clear_pending = true;
+    c->clear_on_own = stream == c->stream;
+    return L3_OK;
+}
+
+// After L3_E_OUTPUT_CAP and a larger output buffer: only the final scatter again.  The scatter counts the tiles it leaves
+// to the generic kernel in the (already cleared) status word, so the word is cleared once more behind it.
+int rerun_emit(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
+    if (c->clear_pending) {
+        c->clear_pending = false;
+        if (!(c->clear_on_own && stream == c->stream)) HIPCHK(c, hipStreamWaitEvent(stream, c->ev_clear, 0));
+    }
+    HIPCHK(c, launch_encode(c->T, W, A, stream, nullptr, true));
+    return queue_status_clear(c, W, stream);
 }
 
 // Runs the pipeline on device-resident data.  On L3_OK or L3_E_OUTPUT_CAP *n_tok is the total.
@@ -181,8 +262,10 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         if (rc) return rc;
         // W.status is all zero here: cleared when the context made it and again after every read-back below, so the
         // clear runs while the host is busy between two calls instead of in front of the kernels
-        if (c->clear_pending && c->clear_stream != stream) HIPCHK(c, hipStreamSynchronize(c->clear_stream));
-        c->clear_pending = false;
+        if (c->clear_pending) {   // (a wait on an event recorded on this same stream is a no-op for the hardware queue)
+            c->clear_pending = false;
+            if (!(c->clear_on_own && stream == c->stream)) HIPCHK(c, hipStreamWaitEvent(stream, c->ev_clear, 0));
+        }
         HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false));
         HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
@@ -191,16 +274,14 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
             HIPCHK(c, launch_emit_generic(W, A, stream));
             HIPCHK(c, hipStreamSynchronize(stream));
         }
-        HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream));
-        c->clear_pending = true;
-        c->clear_stream = stream;
+        if ((rc = queue_status_clear(c, W, stream))) return rc;
         const Status st = *c->h_status;
         if (st.flags & kBadOffsets) {
             c->err = "doc_off must start at 0, be ascending and end at n_bytes";
             return L3_E_INVALID_ARG;
         }
         bool grow = false;
-        if (st.flags & kOvfSlow) { c->slow_cap = (uint64_t)st.slow_count + st.slow_count / 4 + 1024; grow = true; }
+        if (st.flags & kOvfSlow) { c->caps.slow_cap = (uint64_t)st.slow_count + st.slow_count / 4 + 1024; grow = true; }
         uint64_t miss_total = 0, miss_max = 0, mpool_max = 0, mpool_total = 0;
         for (int i = 0; i < kMissShards; i++) {
             miss_total += st.shard[i].miss_count;
@@ -208,13 +289,13 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
             if (st.shard[i].pool_used > mpool_max) mpool_max = st.shard[i].pool_used;
             mpool_total += st.shard[i].pool_used;
         }
-        if (st.flags & kOvfMiss) { c->miss_shard_cap = miss_max + miss_max / 4 + 256; grow = true; }
+        if (st.flags & kOvfMiss) { c->caps.miss_shard_cap = miss_max + miss_max / 4 + 256; grow = true; }
         if (st.flags & kOvfPool) {
-            if (st.pool_used > c->pool_cap) c->pool_cap = st.pool_used + st.pool_used / 4 + 4096;
-            if (mpool_max > c->mpool_shard_cap) c->mpool_shard_cap = mpool_max + mpool_max / 4 + 1024;
+            if (st.pool_used > c->caps.pool_cap) c->caps.pool_cap = st.pool_used + st.pool_used / 4 + 4096;
+            if (mpool_max > c->caps.mpool_shard_cap) c->caps.mpool_shard_cap = mpool_max + mpool_max / 4 + 1024;
             grow = true;
         }
-        if (st.flags & kOvfScratch) { c->scratch_cap = st.scratch_used + st.scratch_used / 4 + (1ull << 20); grow = true; }
+        if (st.flags & kOvfScratch) { c->caps.scratch_cap = st.scratch_used + st.scratch_used / 4 + (1ull << 20); grow = true; }
         if (grow) {
             if (attempt >= 8) { c->err = "workspace did not converge"; return L3_E_HIP; }
             c->counters[4]++;
@@ -252,6 +333,8 @@ int check_offsets_host(l3_ctx* c, const uint64_t* off, uint64_t n) {
 
 }  // namespace
 
+static size_t noalloc_need(uint64_t n_bytes, uint64_t n_docs);
+
 extern "C" {
 
 int l3_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len, int device,
@@ -288,10 +371,19 @@ int l3_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, s
     for (int i = 0; i < kEvCount; i++)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(L3_E_HIP); }
     c->have_events = true;
+    if (hipEventCreateWithFlags(&c->ev_clear, hipEventDisableTiming) != hipSuccess) { c->ev_clear = nullptr; c->err = "hipEventCreate failed"; return fail(L3_E_HIP); }
     if (hipHostMalloc((void**)&c->h_status, sizeof(Status), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_total, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         c->err = "hipHostMalloc failed";
         return fail(L3_E_HIP);
+    }
+    {   // the allocation-free entry point's workspace: its address on THIS device, asked while the device is current
+        hipError_t e = scratch_address(device, &c->na_scratch);
+        if (e != hipSuccess) { c->err = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); return fail(L3_E_HIP); }
+        if (noalloc_need(L3_NOALLOC_MAX_BYTES, L3_NOALLOC_MAX_DOCS) > kNoAllocScratchBytes) {
+            c->err = "internal: L3_NOALLOC_SCRATCH_BYTES does not cover L3_NOALLOC_MAX_BYTES / L3_NOALLOC_MAX_DOCS";
+            return fail(L3_E_HIP);
+        }
     }
     int rc = upload_tables(c);
     if (rc) return fail(rc);
@@ -305,15 +397,14 @@ void l3_destroy(l3_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
-                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_stream, &c->w_items, &c->w_miss, &c->w_missres,
-                      &c->w_extra, &c->w_base, &c->w_pre, &c->w_flag, &c->w_doc0, &c->w_docitem, &c->w_slow, &c->w_pool, &c->w_scratch,
-                      &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
+                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_arena, &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
                       &c->s_total};
     for (DevBuf* b : bufs) b->release();
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->have_events)
         for (int i = 0; i < kEvCount; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_clear) (void)hipEventDestroy(c->ev_clear);
     if (c->have_pipe) {
         for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev_in[i]);
         for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_out[i]); c->p_out[i].release(); c->p_outoff[i].release(); }
@@ -350,6 +441,75 @@ int l3_encode_batch_device(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, c
     int rc = encode_core(c, A, s, n_tok, nullptr);
     if (rc == L3_E_OUTPUT_CAP) c->err = "output buffer too small";
     return rc;
+}
+
+// list capacities of the allocation-free entry point: fixed, sized for its largest batch
+static Caps noalloc_caps() {
+    Caps K = initial_caps(L3_NOALLOC_MAX_BYTES);
+    K.slow_cap *= 2;
+    K.scratch_cap = 8ull << 20;
+    return K;
+}
+// bytes of the array a batch of the largest permitted size takes (status word in front)
+static size_t noalloc_need(uint64_t n_bytes, uint64_t n_docs) {
+    Workspace W{};
+    return ((sizeof(Status) + 255) & ~(size_t)255) + carve_workspace(nullptr, n_bytes, n_docs, noalloc_caps(), nullptr, W);
+}
+
+int l3_encode_batch_device_noalloc(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off,
+                                   uint64_t n_docs, uint32_t flags, int32_t* d_out_tok, uint64_t out_cap,
+                                   uint64_t* d_out_off, uint64_t* n_tok, void* stream) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!d_doc_off || !d_out_off || !n_tok || (!d_text && n_bytes) || (!d_out_tok && out_cap)) {
+        c->err = "null pointer argument";
+        return L3_E_INVALID_ARG;
+    }
+    if (bad_flags(c, flags)) return L3_E_INVALID_ARG;
+    if (n_bytes > (uint64_t)L3_NOALLOC_MAX_BYTES || n_docs > (uint64_t)L3_NOALLOC_MAX_DOCS) {
+        c->err = "batch exceeds the static workspace of l3_encode_batch_device_noalloc (L3_NOALLOC_MAX_BYTES / "
+                 "L3_NOALLOC_MAX_DOCS): split it or use l3_encode_batch_device";
+        return L3_E_INVALID_ARG;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    // calls on one GPU share the array (also across contexts): one at a time
+    std::lock_guard<std::mutex> dev_lk(g_scratch[c->device].mu);
+    const Caps K = noalloc_caps();
+    Workspace W{};
+    unsigned char* const base = c->na_scratch;                     // the device address, not the array's name
+    Status* const status = reinterpret_cast<Status*>(base);        // the status word lives at the front of the array
+    const size_t status_bytes = (sizeof(Status) + 255) & ~(size_t)255;
+    const size_t need = status_bytes + carve_workspace(base + status_bytes, n_bytes, n_docs, K, status, W);
+    if (need > kNoAllocScratchBytes) { c->err = "internal: static workspace too small for its own limits"; return L3_E_INVALID_ARG; }
+    W.bos_id = c->H.special_id[0];
+    W.eos_id = c->H.special_id[1];
+    EncodeArgs A{};
+    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = flags;
+    A.out_tok = d_out_tok; A.out_cap = out_cap; A.out_off = d_out_off; A.kinds = nullptr;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // the array keeps the previous call's contents: the status word (counters, flags, queues) must start at zero; every
+    // other part of the workspace is written before it is read
+    HIPCHK(c, hipMemsetAsync(status, 0, sizeof(Status), s));
+    HIPCHK(c, launch_encode(c->T, W, A, s, nullptr, false));
+    HIPCHK(c, hipMemcpyAsync(c->h_status, status, sizeof(Status), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const Status st = *c->h_status;
+    if (st.flags & kBadOffsets) {
+        c->err = "doc_off must start at 0, be ascending and end at n_bytes";
+        return L3_E_INVALID_ARG;
+    }
+    if (st.flags & (kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) {
+        c->err = "batch needs more workspace than the static array of l3_encode_batch_device_noalloc holds (unusually many "
+                 "deferred pre-tokens): use l3_encode_batch_device";
+        return L3_E_SCRATCH;
+    }
+    *n_tok = st.total_tokens;
+    if (st.flags & kOvfOut) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
+    if (st.generic_tiles) {
+        HIPCHK(c, launch_emit_generic(W, A, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    return L3_OK;
 }
 
 // page-locked host memory (hipHostMalloc / hipHostRegister), which the copy engines reach directly
@@ -429,9 +589,8 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
             HIPCHK(c, ob.ensure(tk * 4));
             A.out_tok = ob.as<int32_t>();
             A.out_cap = ob.cap / 4;
-            HIPCHK(c, launch_encode(c->T, W, A, c->stream, nullptr, true));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            rc = L3_OK;
+            rc = rerun_emit(c, W, A, c->stream);
+            if (rc == L3_OK && hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "hipStreamSynchronize failed"; rc = L3_E_HIP; }
         }
         if (rc) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamSynchronize(c->stream_out); return rc; }
         for (int i = 0; i < 6; i++) sum_counters[i] += c->counters[i];
@@ -484,8 +643,7 @@ int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uin
         HIPCHK(c, c->s_out.ensure(total * 4));
         A.out_tok = c->s_out.as<int32_t>();
         A.out_cap = c->s_out.cap / 4;
-        HIPCHK(c, launch_encode(c->T, W, A, s, nullptr, true));
-        rc = L3_OK;
+        rc = rerun_emit(c, W, A, s);
     }
     if (rc) return rc;
     *n_tok = total;

@@ -2175,6 +2175,7 @@ __device__ void emit_tile_generic(const Workspace& W, const EncodeArgs& A, uint6
             } else {
                 uint32_t qi = atomicAdd(&q_n, 1u);
                 if (qi < kEmitQueue) { q_out[qi] = o; q_item[qi] = item; }
+                else for (uint32_t k = 0; k < cnt; k++) A.out_tok[o + k] = deferred_token(W, poff, inl, k);   // queue full: the owner copies
             }
         }
     }
@@ -2186,8 +2187,9 @@ __device__ void emit_tile_generic(const Workspace& W, const EncodeArgs& A, uint6
         if (bos && d < A.n_docs) A.out_tok[off] = W.bos_id;
         if (eos && d > 0) A.out_tok[off - 1] = W.eos_id;
     }
-    // long runs of tokens from the pool: copied by the whole workgroup (a pre-token with more than 64
-    // tokens has more than 21 bytes, so one tile holds fewer than kEmitQueue of them)
+    // long runs of tokens from the pool: copied by the whole workgroup.  (A pre-token of more than 64 tokens has at least
+    // 22 bytes -- an invalid byte is three symbols --, so a tile can hold 174 of them: what the queue does not take its
+    // owner has copied above.)
     const uint32_t qn = q_n < kEmitQueue ? q_n : kEmitQueue;
     for (uint32_t qi = 0; qi < qn; qi++) {
         uint64_t po; uint32_t cn; bool il;

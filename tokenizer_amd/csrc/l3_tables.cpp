@@ -180,11 +180,22 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
         std::unordered_map<uint64_t, int> seen;
         seen.reserve(1 << 19);
         uint32_t last_merged = 0, sub = 0;
+        bool tail = false;   // a rule whose product is not in the vocabulary has been seen
         while (br.has(34)) {
             uint32_t a = br.get(17), b = br.get(17);
-            if ((int)a >= n_base || (int)b >= n_base) { T.error = "merge rule references an unknown token id"; return false; }
+            // decoder.go:61-63 skips a pair that names an id beyond the token list (base vocabulary + special tokens); a pair
+            // that names a special token is kept there but can never apply: symbol lists hold base tokens only
+            if ((int)a >= n_base || (int)b >= n_base) continue;
             auto it = by_bytes.find(tok((int)a) + tok((int)b));
-            if (it == by_bytes.end() || it->second >= n_base) { T.error = "merge rule whose product is not in the vocabulary"; return false; }
+            if (it == by_bytes.end()) {
+                // The reference keeps such a rule; when it fires the two operands are frozen and nothing is produced
+                // (bpe.go:157-161).  With every such rule ranked after every productive one -- a truncated vocabulary with
+                // the full merge file -- they fire only once no productive rule applies any more and change no output: dropped.
+                tail = true;
+                continue;
+            }
+            if (tail) { T.error = "a merge rule whose product is not in the vocabulary precedes productive rules (unsupported)"; return false; }
+            if (it->second >= n_base) { T.error = "merge rule whose product is a special token"; return false; }
             uint32_t m = (uint32_t)it->second;
             if (!seen.emplace(pair_key(a, b), 1).second) { T.error = "duplicate merge rule"; return false; }
             if (!rules.empty() && m < last_merged) { T.error = "merge rules are not grouped by ascending product id"; return false; }

@@ -38,3 +38,13 @@ def gather_counts(dist, n_tok, n_docs, device=None):
     allc = allc.cpu().numpy().reshape(world, 2)
     r = dist.get_rank()
     return int(allc[:r, 0].sum()), int(allc[:r, 1].sum()), (int(allc[:, 0].sum()), int(allc[:, 1].sum()))
+
+
+def corpus_batches(config, rank, world, steps, total_batches):
+    """Batches (of 65,536 documents) of the C5 corpus that `rank` encodes, in order (bench.py).
+    "c5": the whole corpus of `total_batches`, each rank one contiguous range of whole batches (strong scaling: the ranges
+    are disjoint and cover the corpus).  "c2": `steps` batches per rank, step s of rank r = batch s * world + r (weak
+    scaling: every step the ranks take `world` consecutive batches)."""
+    if config == "c5":
+        return list(range(total_batches * rank // world, total_batches * (rank + 1) // world))
+    return [s * world + rank for s in range(steps)]

@@ -14,15 +14,24 @@ SRC = os.path.join(ROOT, "tools", "l3_corpus.c")
 LIB = os.path.join(ROOT, "tokenizer_amd", "lib", "libl3corpus.so")
 DATA = os.path.join(ROOT, "tokenizer_amd", "data")
 
+DEV_SRC = os.path.join(ROOT, "tools", "l3_corpus_dev.hip")
+DEV_LIB = os.path.join(ROOT, "tokenizer_amd", "lib", "libl3corpusdev.so")
+
 _lib = None
+_dev_lib = None
 _words = None
+_dev_words = {}
 
 
 def build():
-    if os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
-        return LIB
+    """Builds the host generators and (where hipcc exists: in the build container, not on the GPU box, which gets the
+    built file with the tree) the device generator."""
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", LIB, SRC])
+    if not (os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC)):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", LIB, SRC])
+    if not (os.path.exists(DEV_LIB) and os.path.getmtime(DEV_LIB) >= os.path.getmtime(DEV_SRC)):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-o", DEV_LIB, DEV_SRC])
     return LIB
 
 
@@ -62,6 +71,31 @@ def english(n_docs, doc_bytes=1024, first_doc=0):
     _load().l3c_gen_english(first_doc, n_docs, doc_bytes, blob.ctypes.data, off.ctypes.data, thr.ctypes.data, n,
                             out.ctypes.data)
     return out, (np.arange(n_docs + 1, dtype=np.uint64) * np.uint64(doc_bytes))
+
+
+def english_device(d_out, first_doc, n_docs, doc_bytes=1024, stream=None):
+    """C2 / C5 documents first_doc .. first_doc + n_docs generated ON THE GPU into the torch uint8 CUDA tensor d_out
+    (n_docs * doc_bytes bytes): the same bytes english() returns for the same documents, without a host buffer."""
+    global _dev_lib
+    import torch
+    if _dev_lib is None:
+        if not os.path.exists(DEV_LIB):
+            build()
+        _dev_lib = C.CDLL(DEV_LIB)
+        _dev_lib.l3c_gen_english_device.restype = C.c_int
+        _dev_lib.l3c_gen_english_device.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_uint32, C.c_void_p, C.c_void_p]
+    dev = d_out.device.index
+    if dev not in _dev_words:
+        blob, off, thr, n = word_list()
+        _dev_words[dev] = (torch.from_numpy(blob).to(d_out.device), torch.from_numpy(off.astype(np.int32)).to(d_out.device),
+                           torch.from_numpy(thr.view(np.int64)).to(d_out.device), n)
+    w, wo, cdf, n = _dev_words[dev]
+    assert d_out.dtype == torch.uint8 and d_out.is_contiguous() and d_out.numel() >= n_docs * doc_bytes
+    rc = _dev_lib.l3c_gen_english_device(first_doc, n_docs, doc_bytes, w.data_ptr(), wo.data_ptr(), cdf.data_ptr(), n,
+                                         d_out.data_ptr(), stream)
+    if rc != 0:
+        raise RuntimeError("l3c_gen_english_device failed: HIP error %d" % rc)
 
 
 def multilingual(n_docs, doc_bytes=4 << 20, max_run=4096, first_doc=0):
