@@ -40,6 +40,7 @@ def test_device_generator_writes_the_host_generator_s_bytes():
 
 def _encode_resident(ctx, torch, d_text, n_bytes, d_off, n_docs, d_out, d_out_off):
     from tokenizer_amd import capi
+    torch.cuda.synchronize()    # the generator ran on the default stream; the context's own stream does not wait for that one
     rc, n = ctx.encode_batch_device(d_text.data_ptr(), n_bytes, d_off.data_ptr(), n_docs, 3, d_out.data_ptr(), d_out.numel(),
                                     d_out_off.data_ptr(), None)
     assert rc == capi.L3_OK, ctx._err(rc)
