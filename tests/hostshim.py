@@ -32,6 +32,8 @@ class HostShim:
         L.l3t_vocab_lookup.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
         L.l3t_bpe.restype = C.c_int64
         L.l3t_bpe.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.l3t_bpe_pieces.restype = C.c_int64
+        L.l3t_bpe_pieces.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
         L.l3t_bpe_rounds.restype = C.c_int64
         L.l3t_bpe_rounds.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
         L.l3t_token_bytes.restype = C.c_int64
@@ -76,6 +78,15 @@ class HostShim:
         nr = C.c_int64(0)
         n = self.lib.l3t_bpe_rounds(self.h, raw, len(raw), out.ctypes.data, cap, C.byref(nr))
         return out[:n].tolist(), nr.value
+
+    def bpe_pieces(self, raw: bytes):
+        """PerformBPE piece by piece, cut where no vocabulary entry can span (the slow kernel's way with long
+        pre-tokens).  Returns (ids, pieces)."""
+        cap = len(raw) + 1
+        out = np.empty(cap, dtype=np.int32)
+        npc = C.c_int64(0)
+        n = self.lib.l3t_bpe_pieces(self.h, raw, len(raw), out.ctypes.data, cap, C.byref(npc))
+        return out[:n].tolist(), npc.value
 
     def token_bytes(self, tid):
         buf = np.empty(160, dtype=np.uint8)

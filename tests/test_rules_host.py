@@ -150,3 +150,30 @@ def test_round_based_merge_is_exact(shim, oracle):
             total_rounds += nr
             total_merges += len(w) - len(got)
     assert total_rounds < total_merges  # rounds really do batch several merges
+
+
+def test_cutting_long_pretokens_is_exact(shim, oracle):
+    """Pre-tokens cut at the positions no vocabulary entry can span (l3_common.h: prefix tables, reach, cuts), every
+    piece merged on its own, against the oracle's PerformBPE of the whole pre-token (heap, linked list, whole-string
+    shortcut): ideographs, Cyrillic, byte soup incl. U+FFFD expansions, words glued together, runs, every single token."""
+    rng = random.Random(23)
+    cases = [corpus.random_word(rng, lo=2, hi=60) for _ in range(20000)]
+    cases += ["".join(chr(rng.randrange(0x4E00, 0x9FA5)) for _ in range(rng.randint(1, 400))).encode() for _ in range(1500)]
+    cases += ["".join(chr(rng.randrange(0x410, 0x450)) for _ in range(rng.randint(1, 200))).encode() for _ in range(1000)]
+    cases += ["".join(chr(rng.randrange(0x1F300, 0x1F700)) for _ in range(rng.randint(1, 60))).encode() for _ in range(500)]
+    cases += [corpus.random_bytes_doc(rng, rng.randint(2, 300)).decode("utf-8", "replace").encode() for _ in range(4000)]
+    cases += [corpus.random_bytes_doc(rng, rng.randint(2, 300)) for _ in range(3000)]        # raw bytes as symbols
+    cases += [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(2, 300))) for _ in range(3000)]
+    cases += [bytes(rng.choice(b"!@#$%^&*()-=+[]{};:,.<>/?") for _ in range(rng.randint(2, 300))) for _ in range(2000)]
+    words = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "words_4096.txt")).read().split()
+    cases += ["".join(rng.choice(words) for _ in range(rng.randint(2, 40))).encode() for _ in range(2000)]
+    cases += [b"a" * k for k in range(2, 70)] + [b"ab" * 500, b"aab" * 300, b" " * 1000, b"\t" * 777, b"!" * 999, b"\xef\xbf\xbd" * 300]
+    cases += ["中文".encode() * 300, ("ab" * 40 + "c").encode() * 30, "пример".encode() * 90 + "汉".encode() * 50]
+    cases += [shim.token_bytes(t) for t in range(256, 128000, 7)]                              # whole-string hits
+    pieces = cut_cases = 0
+    for w in cases:
+        got, npc = shim.bpe_pieces(w)
+        assert got == oracle.bpe_raw(w), w
+        pieces += npc
+        cut_cases += npc > 1
+    assert cut_cases > 10000 and pieces > 100000    # the cuts are really exercised

@@ -74,7 +74,7 @@ struct l3_ctx {
     int device = 0;
     HostTables H;
     Tables T{};
-    DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes;
+    DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes, t_prefix2, t_bloom;
     // The status word is cleared AFTER a call has read it back (so the clear runs between two calls, not in front of the
     // kernels).  The clear is ordered before the next call's kernels by an event the context owns: the caller's stream
     // handle is never kept, it may be destroyed between two calls.
@@ -136,6 +136,8 @@ int upload_tables(l3_ctx* c) {
     if ((rc = upload(c, c->t_special, H.special_id, 256))) return rc;
     if ((rc = upload(c, c->t_tokoff, H.tok_off.data(), H.tok_off.size()))) return rc;
     if ((rc = upload(c, c->t_tokbytes, H.tok_bytes.data(), H.tok_bytes.size()))) return rc;
+    if ((rc = upload(c, c->t_prefix2, H.prefix2.data(), H.prefix2.size()))) return rc;
+    if ((rc = upload(c, c->t_bloom, H.prefix_bloom.data(), H.prefix_bloom.size()))) return rc;
     Tables& T = c->T;
     T.cls_stage1 = c->t_cls1.as<uint16_t>();
     T.cls_blocks = c->t_clsb.as<uint8_t>();
@@ -145,8 +147,11 @@ int upload_tables(l3_ctx* c) {
     T.vocab_slots = c->t_vslots.as<VocabSlot>();
     T.vocab_blob = c->t_vblob.as<uint32_t>();
     T.special_id = c->t_special.as<int32_t>();
+    T.prefix2 = c->t_prefix2.as<uint32_t>();
+    T.prefix_bloom = c->t_bloom.as<uint32_t>();
     T.pair_log2 = H.pair_log2;
     T.vocab_log2 = H.vocab_log2;
+    T.bloom_log2 = H.bloom_log2;
     return L3_OK;
 }
 
@@ -397,7 +402,7 @@ void l3_destroy(l3_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
-                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->w_arena, &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
+                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->t_prefix2, &c->t_bloom, &c->w_arena, &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
                       &c->s_total};
     for (DevBuf* b : bufs) b->release();
     if (c->h_status) (void)hipHostFree(c->h_status);

@@ -92,6 +92,40 @@ L3_HD void strhash_buckets(const StrHash& h, uint32_t len, uint32_t log2_buckets
     *b2 = mix32(h.h2 + len * 0x85EBCA6Bu + 0x68E31DA4u) >> (32 - log2_buckets);
 }
 
+// ---- cut points inside long pre-tokens --------------------------------------------------------------------------
+// Every symbol BPE ever creates is a vocabulary entry (a merge rule's product is one), and a symbol's bytes are a
+// substring of the pre-token.  So if NO vocabulary entry equals a substring x[a..b) with a < p < b, no merge can ever join
+// the symbols left and right of byte position p: the greedy merge loop (bpe.go:49-59) of the pre-token is the merge loop
+// of x[0..p) and of x[p..n) run independently (merges on one side never change a pair on the other, and the pair across
+// p never has a rule), and their results concatenated.  Such a p is a CUT.
+//   reach(s) = s + (length of the longest vocabulary entry that is a prefix of x[s..n))   (>= s + 1: single bytes)
+//   p is a cut  <=>  max over s < p of reach(s) <= p.
+// The tables answer "is x[s..s+k) a PREFIX of some vocabulary entry": exactly for k = 2 (65,536 bits), by a one-hash
+// Bloom filter for k >= 3.  A false positive only lengthens a match: reach is then an over-estimate, cuts get fewer,
+// and every cut found is still a true cut.  (Whole pre-token shortcut, bpe.go:27-33: a pre-token with a cut is no
+// vocabulary entry, so only cut-free pre-tokens are probed as a whole.)
+constexpr int kPrefix2Words = 65536 / 32;
+L3_HD uint32_t cut_hash2(uint32_t a, uint32_t b) { return ((a << 8) | b) * 0x9E3779B1u + 0x7F4A7C15u; }   // state after two bytes
+L3_HD uint32_t cut_hash_add(uint32_t h, uint32_t byte) { h = (h ^ (byte + 1u)) * 0x85EBCA6Bu; return h ^ (h >> 15); }
+L3_HD uint32_t cut_hash_bit(uint32_t h, uint32_t log2_bits) { return (h * 0xC2B2AE35u) >> (32 - log2_bits); }
+// length of the longest string x[0..k), k <= n, that the tables accept as a prefix of a vocabulary entry (k >= 1);
+// get(i) = byte i.  n = bytes available (up to the end of the pre-token).
+template <class Get>
+L3_HD uint32_t cut_match_len(const uint32_t* prefix2, const uint32_t* bloom, uint32_t bloom_log2, Get get, uint32_t n) {
+    if (n < 2) return n;
+    const uint32_t a = get(0), b = get(1);
+    if (!((prefix2[(a << 3) | (b >> 5)] >> (b & 31u)) & 1u)) return 1;
+    uint32_t len = 2, h = cut_hash2(a, b);
+    while (len < n && len < (uint32_t)kMaxTokenBytes) {
+        const uint32_t h2 = cut_hash_add(h, get(len));
+        const uint32_t bit = cut_hash_bit(h2, bloom_log2);
+        if (!((bloom[bit >> 5] >> (bit & 31u)) & 1u)) break;
+        h = h2;
+        len++;
+    }
+    return len;
+}
+
 // ---- character classes ------------------------------------------------------------------------
 // two-stage table: stage1[cp >> 8] -> block; block = 64 bytes, 2 bits per code point:
 // 0 other, 1 letter (L*), 2 decimal digit (Nd), 3 white space (unicode.IsSpace)
@@ -107,8 +141,11 @@ struct Tables {
     const VocabSlot* vocab_slots; // [1 << vocab_log2]
     const uint32_t* vocab_blob;   // raw bytes of tokens longer than kVocabInline, as zero-padded words
     const int32_t* special_id;    // [256] canonical special index -> token id (0 = not a token)
+    const uint32_t* prefix2;      // [kPrefix2Words] bit (a << 8 | b): some vocabulary entry starts with the bytes a b
+    const uint32_t* prefix_bloom; // [1 << (bloom_log2 - 5)] one-hash Bloom filter of the prefixes of 3 and more bytes
     uint32_t pair_log2;
     uint32_t vocab_log2;
+    uint32_t bloom_log2;
 };
 
 // canonical special index: 0..7 = the named tokens in regex order (special.go:12), 8+k = reserved_k

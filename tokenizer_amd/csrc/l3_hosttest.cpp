@@ -50,6 +50,9 @@ void* l3t_create(const void* vocab, size_t vlen, const void* merges, size_t mlen
     h->T.special_id = h->H.special_id;
     h->T.pair_log2 = h->H.pair_log2;
     h->T.vocab_log2 = h->H.vocab_log2;
+    h->T.prefix2 = h->H.prefix2.data();
+    h->T.prefix_bloom = h->H.prefix_bloom.data();
+    h->T.bloom_log2 = h->H.bloom_log2;
     return h;
 }
 void l3t_destroy(void* p) { delete (Handle*)p; }
@@ -249,6 +252,38 @@ int64_t l3t_bpe_rounds(void* hp, const uint8_t* bytes, int64_t n0, int32_t* out,
     if (rounds) *rounds = nr;
     for (size_t i = 0; i < n && (int64_t)i < cap; i++) out[i] = sa[i];
     return (int64_t)n;
+}
+
+// PerformBPE of one pre-token (raw, already U+FFFD-expanded bytes) PIECE BY PIECE: the pre-token is cut at the positions
+// no vocabulary entry can span (l3_common.h, cut_match_len) and every piece is merged on its own; a pre-token without a
+// cut goes through the whole-string probe first, as l3t_bpe does.  This is what the slow kernel does with long
+// pre-tokens; the CPU suite fuzzes it against the oracle.  *n_pieces receives the number of pieces.
+int64_t l3t_bpe_pieces(void* hp, const uint8_t* bytes, int64_t n, int32_t* out, int64_t cap, int64_t* n_pieces) {
+    Handle* h = (Handle*)hp;
+    const Tables& T = h->T;
+    std::vector<int64_t> starts;
+    int64_t reach = 0;
+    for (int64_t s = 0; s < n; s++) {
+        if (reach <= s) starts.push_back(s);    // (s == 0 included)
+        const uint32_t m = cut_match_len(T.prefix2, T.prefix_bloom, T.bloom_log2, [&](uint32_t i) { return (uint32_t)bytes[s + i]; },
+                                         (uint32_t)(n - s < 1000 ? n - s : 1000));
+        if (s + m > reach) reach = s + m;
+    }
+    starts.push_back(n);
+    if (n_pieces) *n_pieces = (int64_t)starts.size() - 1;
+    if (starts.size() <= 2) return l3t_bpe(hp, bytes, n, out, cap);
+    int64_t k = 0;
+    for (size_t pi = 0; pi + 1 < starts.size(); pi++) {
+        const int64_t a = starts[pi], len = starts[pi + 1] - a;
+        std::vector<int32_t> sym((size_t)len);
+        std::vector<uint32_t> pr((size_t)len, kNoPrio);
+        for (int64_t i = 0; i < len; i++) sym[i] = T.byte_tok[bytes[a + i]];
+        for (int64_t i = 0; i + 1 < len; i++) pr[i] = T.bytepair[((uint32_t)bytes[a + i] << 8) | bytes[a + i + 1]];
+        merge_span(T, sym, pr, 0, (int)len);
+        for (int64_t i = 0; i < len; i++)
+            if (sym[i] >= 0) { if (k < cap) out[k] = sym[i]; k++; }
+    }
+    return k;
 }
 
 // Decode table access for tests: raw bytes of token id (tokenizer.go:339-354)

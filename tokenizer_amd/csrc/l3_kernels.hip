@@ -1262,10 +1262,6 @@ struct MidLds {  // one wave's share of the arena
     int32_t sA[kMidSyms], sB[kMidSyms];
     uint32_t pA[kMidSyms], pB[kMidSyms];
 };
-union SlowLds {
-    RegionLds R;
-    MergeLds M;
-};
 constexpr int32_t kIdMask = 0x1FFFF;
 constexpr int32_t kSelBit = 1 << 30;
 constexpr int32_t kDirtyBit = 1 << 29;
@@ -1677,8 +1673,99 @@ __device__ void mid_pass(const Tables& T, const Workspace& W, const EncodeArgs& 
     }
 }
 
+// ---- long pre-tokens piece by piece ------------------------------------------------------------------------
+// A long pre-token is cut at the positions no vocabulary entry can span (l3_common.h: prefix tables, reach, cuts); the
+// pieces are independent BPE problems.  Ideographs, byte soup and most non-Latin text fall into pieces of a few bytes,
+// which single lanes merge in LDS slots as merge_kernel does; only a piece of more than kLaneMax symbols (glued words,
+// one character repeated) still needs the round-based merge below.  Results go into an IMAGE of the pre-token in the slow
+// pool -- one int32 slot per symbol, piece p's tokens at the slots of its first symbols, -1 in the others --, which no
+// piece shares with another (so pieces can be done in any order), and the image is compacted in place at the end.
+constexpr int kWin = 4096;                       // symbols examined per window: 16 consecutive ones per thread
+constexpr int kWinPer = kWin / kSlowThreads;
+constexpr int kWinAhead = kMaxTokenBytes;        // a match looks at most this far ahead
+static_assert(kWinPer == 16, "cut masks are 16 bits per thread");
+struct PieceLds {
+    uint8_t wb[kWin + kWinAhead + 16];           // the window's symbols (bytes) + look-ahead
+    uint16_t cutw[kSlowThreads];                 // cut bits of each thread's 16 positions
+    uint16_t pl[kWin + 2];                       // piece starts (window-local), ascending
+    uint32_t tmp[16];
+    uint32_t vars[8];
+};
+union SlowLds {
+    RegionLds R;                                 // finding the end of an open-ended pre-token
+    MergeLds M;                                  // round-based merge of a long piece
+    uint32_t arena[2 * kMergeArena];             // lane slots of the short pieces
+};
+
+// Round-based merge of the piece [q, q + n) of the symbol bytes `sp`, by the whole workgroup; `whole`: the piece is the
+// entire pre-token (then the whole-string probe of bpe.go:27-33 comes first).  Tokens go to img[q ..], -1 behind them.
+__device__ __noinline__ void rounds_piece(const Tables& T, const Workspace& W, SlowLds& S, const uint8_t* sp, uint64_t q, uint32_t n,
+                                          bool whole, int32_t* img, uint32_t* tmp, unsigned long long* tmp64, Seg* segtmp,
+                                          long long* lvars, uint8_t* xb) {
+    const int tid = threadIdx.x;
+    int32_t *sa, *sb;
+    uint32_t *pa, *pb;
+    __syncthreads();   // the union is free: everybody is done with the lane slots / the region image
+    if (n <= (uint32_t)kSlowLds) {
+        sa = S.M.sA; sb = S.M.sB; pa = S.M.pA; pb = S.M.pB;
+    } else {
+        if (tid == 0) {
+            const unsigned long long need = (unsigned long long)n * 16ull;
+            const unsigned long long off = atomicAdd(&W.status->scratch_used, need);
+            lvars[2] = (off + need <= W.scratch_cap) ? (long long)off : -1ll;
+            if (off + need > W.scratch_cap) atomicOr(&W.status->flags, kOvfScratch);
+        }
+        __syncthreads();
+        const long long off = lvars[2];
+        if (off < 0) return;   // (uniform) the host grows the scratch and runs the batch again
+        uint8_t* base = W.scratch + off;
+        sa = reinterpret_cast<int32_t*>(base);
+        sb = sa + n;
+        pa = reinterpret_cast<uint32_t*>(sb + n);
+        pb = pa + n;
+    }
+    for (uint32_t i = (uint32_t)tid; i < n; i += kSlowThreads) sa[i] = sp[q + i];
+    __syncthreads();
+    int32_t whole_id = -1;
+    if (whole && n <= (uint32_t)kMaxTokenBytes) {  // bpe.go:27-33
+        if ((uint32_t)tid < n) xb[tid] = (uint8_t)sa[tid];
+        __syncthreads();
+        if (tid == 0) lvars[3] = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)xb[i]; }, n);
+        __syncthreads();
+        whole_id = (int32_t)lvars[3];
+    }
+    uint32_t n_out;
+    if (whole_id >= 0) {
+        n_out = 1;
+        if (tid == 0) sa[0] = whole_id;
+        __syncthreads();
+    } else {
+        for (uint32_t i = (uint32_t)tid; i < n; i += kSlowThreads)
+            pa[i] = i + 1 < n ? T.bytepair[((uint32_t)sa[i] << 8) | (uint32_t)sa[i + 1]] : kNoPrio;
+        __syncthreads();
+        for (uint32_t i = (uint32_t)tid; i < n; i += kSlowThreads) sa[i] = T.byte_tok[sa[i]];
+        __syncthreads();
+        n_out = merge_rounds<false>(T, sa, pa, sb, pb, n, tmp, tmp64, segtmp);
+    }
+    for (uint32_t i = (uint32_t)tid; i < n; i += kSlowThreads) img[q + i] = i < n_out ? (sa[i] & kIdMask) : -1;
+    __syncthreads();
+}
+
+// Tokens of a finished lane slot to the image: piece [q, q + len)
+__device__ __forceinline__ void slot_to_image(const uint32_t* sy, int32_t* img, uint64_t q, uint32_t len) {
+    uint32_t p = 0, k = 0;
+    while (p != kNone) {
+        const uint32_t w = sy[p];
+        img[q + k++] = (int32_t)(w & 0x1FFFFu);
+        p = (w >> 17) & 127u;
+    }
+    for (; k < len; k++) img[q + k] = -1;
+}
+
 __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace W, EncodeArgs A) {
     __shared__ __align__(16) SlowLds S;
+    __shared__ __align__(16) PieceLds P;
+    __shared__ uint8_t byte_tok[256];
     __shared__ uint32_t tmp[16];
     __shared__ unsigned long long tmp64[8];
     __shared__ Seg segtmp[4];
@@ -1690,6 +1777,9 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
     const int tid = threadIdx.x;
     const uint32_t n_big = W.status->slow_q.count;  // final: mid_kernel has run
     if (blockIdx.x >= n_big) return;
+    for (int i = tid; i < 256; i += kSlowThreads) byte_tok[i] = T.byte_tok[i];
+    uint32_t* const sy_a = S.arena;
+    uint32_t* const pq_a = S.arena + kMergeArena;
     bool first = true;  // the first entry needs no counter: workgroup g starts at g
     // Entries of known, moderate length were mid_kernel's; the rest, a workgroup per entry:
     // The entries differ in length by three orders of magnitude, so they are handed out one at a time from a counter
@@ -1776,30 +1866,27 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
             L += x;
         }
         __syncthreads();
-        int32_t *sa, *sb;
-        uint32_t *pa, *pb;
-        bool ok = true;
-        if (L <= (uint32_t)kSlowLds) {
-            sa = S.M.sA; sb = S.M.sB; pa = S.M.pA; pb = S.M.pB;
-        } else {
-            if (tid == 0) {
-                unsigned long long need = (unsigned long long)L * 16ull;
-                unsigned long long off = atomicAdd(&W.status->scratch_used, need);
-                lvars[2] = (off + need <= W.scratch_cap) ? (long long)off : -1ll;
-                if (off + need > W.scratch_cap) atomicOr(&W.status->flags, kOvfScratch);
+        // room: L image slots in the slow pool; the expanded bytes of a pre-token with invalid UTF-8 in the scratch
+        const bool has_inv = (uint64_t)L != len;
+        if (tid == 0) {
+            const unsigned long long off = atomicAdd(&W.status->pool_used, (unsigned long long)L);
+            const bool fits = off + L <= W.pool_cap;
+            if (!fits) atomicOr(&W.status->flags, kOvfPool);
+            lvars[4] = fits ? (long long)off : -1ll;
+            lvars[5] = 0;
+            if (has_inv) {
+                const unsigned long long need = ((unsigned long long)L + 31ull) & ~15ull;
+                const unsigned long long so2 = atomicAdd(&W.status->scratch_used, need);
+                lvars[5] = (so2 + need <= W.scratch_cap) ? (long long)so2 : -1ll;
+                if (so2 + need > W.scratch_cap) atomicOr(&W.status->flags, kOvfScratch);
             }
-            __syncthreads();
-            long long off = lvars[2];
-            ok = off >= 0;
-            uint8_t* base = W.scratch + (ok ? off : 0);
-            sa = reinterpret_cast<int32_t*>(base);
-            sb = sa + L;
-            pa = reinterpret_cast<uint32_t*>(sb + L);
-            pb = pa + L;
         }
-        uint32_t n_out = 0;
-        if (ok) {
-            // symbol bytes first, then pair priorities, then ids
+        __syncthreads();
+        if (lvars[4] < 0 || lvars[5] < 0) continue;   // (uniform) the host grows the lists and runs the batch again
+        int32_t* const img = W.pool + (unsigned long long)kMissShards * W.mpool_shard_cap + (unsigned long long)lvars[4];
+        const uint8_t* sp = A.text + start;
+        if (has_inv) {
+            uint8_t* xs = W.scratch + lvars[5];
             uint32_t o = so;
             for (uint64_t base = b0; base < b1; base += 64) {
                 const uint64_t q = base + lane;
@@ -1808,50 +1895,239 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
                 const unsigned long long mi = __ballot(in), mv = __ballot(inv);
                 const uint32_t pos = o + (uint32_t)__popcll(mi & lt) + 2u * (uint32_t)__popcll(mv & lt);
                 if (inv) {
-                    sa[pos] = 0xEF; sa[pos + 1] = 0xBF; sa[pos + 2] = 0xBD;
+                    xs[pos] = 0xEF; xs[pos + 1] = 0xBF; xs[pos + 2] = 0xBD;
                 } else if (in) {
-                    sa[pos] = A.text[start + q];
+                    xs[pos] = A.text[start + q];
                 }
                 o += (uint32_t)__popcll(mi) + 2u * (uint32_t)__popcll(mv);
             }
+            sp = xs;
             __syncthreads();
-            int32_t whole = -1;
-            if (L <= (uint32_t)kMaxTokenBytes) {  // bpe.go:27-33
-                if ((uint32_t)tid < L) xb[tid] = (uint8_t)sa[tid];
-                __syncthreads();
-                if (tid == 0) lvars[3] = vocab_lookup(T, [&](uint32_t i) { return (uint32_t)xb[i]; }, L);
-                __syncthreads();
-                whole = (int32_t)lvars[3];
-            }
-            if (whole >= 0) {
-                if (tid == 0) sa[0] = whole;
-                n_out = 1;
-                __syncthreads();
-            } else {
-                for (uint32_t i = (uint32_t)tid; i < L; i += kSlowThreads)
-                    pa[i] = i + 1 < L ? T.bytepair[((uint32_t)sa[i] << 8) | (uint32_t)sa[i + 1]] : kNoPrio;
-                __syncthreads();
-                for (uint32_t i = (uint32_t)tid; i < L; i += kSlowThreads) sa[i] = T.byte_tok[sa[i]];
-                __syncthreads();
-                n_out = merge_rounds<false>(T, sa, pa, sb, pb, L, tmp, tmp64, segtmp);
-            }
-            // ---- 3. tokens to the pool
-            if (tid == 0) {
-                unsigned long long off = atomicAdd(&W.status->pool_used, (unsigned long long)n_out);
-                bool fits = off + n_out <= W.pool_cap;
-                if (!fits) atomicOr(&W.status->flags, kOvfPool);
-                lvars[4] = fits ? (long long)off : -1ll;
-                W.slow[ei].count = n_out;
-                W.slow[ei].pool_off = (unsigned long long)kMissShards * W.mpool_shard_cap + off;
-                if (n_out > 1) atomicAdd(&W.tile_extra[W.slow[ei].tile], n_out - 1);
+        }
+        // ---- 3. windows: cuts, pieces, merges
+        uint32_t open_start = 0, w0 = 0, carry = 0;   // symbol positions; carry = furthest reach of the positions before w0
+#pragma unroll 1
+        while (w0 < L) {
+            const uint32_t n = L - w0 < (uint32_t)kWin ? L - w0 : (uint32_t)kWin;
+            const uint32_t avail = L - w0 < (uint32_t)(kWin + kWinAhead) ? L - w0 : (uint32_t)(kWin + kWinAhead);
+            __syncthreads();
+            for (uint32_t i = (uint32_t)tid * 16u; i < avail + 16u && i < (uint32_t)sizeof(P.wb); i += kSlowThreads * 16u) {
+                const uint8_t* src = sp + w0 + i;
+                if (i + 16u <= avail && (((uintptr_t)src) & 15u) == 0) {
+                    *reinterpret_cast<uint4*>(&P.wb[i]) = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    for (uint32_t k = 0; k < 16u; k++) P.wb[i + k] = i + k < avail ? src[k] : (uint8_t)0;
+                }
             }
             __syncthreads();
-            if (lvars[4] >= 0) {
-                int32_t* dst = W.pool + (unsigned long long)kMissShards * W.mpool_shard_cap + lvars[4];
-                for (uint32_t i = tid; i < n_out; i += kSlowThreads) dst[i] = sa[i] & kIdMask;
+            // match length at each of this thread's 16 consecutive positions, all walks in step (independent loads)
+            const uint32_t p0 = (uint32_t)tid * (uint32_t)kWinPer;
+            uint32_t mlen[kWinPer], hh[kWinPer];
+            uint32_t alive = 0;
+#pragma unroll
+            for (int j = 0; j < kWinPer; j++) {
+                const uint32_t p = p0 + (uint32_t)j;
+                mlen[j] = 1; hh[j] = 0;
+                if (p < n && p + 1 < avail) {
+                    const uint32_t a = P.wb[p], b = P.wb[p + 1];
+                    if ((T.prefix2[(a << 3) | (b >> 5)] >> (b & 31u)) & 1u) { mlen[j] = 2; hh[j] = cut_hash2(a, b); alive |= 1u << j; }
+                }
             }
+            while (alive) {
+                uint32_t word[kWinPer], h2[kWinPer];
+#pragma unroll
+                for (int j = 0; j < kWinPer; j++) {
+                    word[j] = 0; h2[j] = 0;
+                    if ((alive >> j) & 1u) {
+                        const uint32_t p = p0 + (uint32_t)j;
+                        if (p + mlen[j] < avail && mlen[j] < (uint32_t)kMaxTokenBytes) {
+                            h2[j] = cut_hash_add(hh[j], P.wb[p + mlen[j]]);
+                            const uint32_t bit = cut_hash_bit(h2[j], T.bloom_log2);
+                            word[j] = (T.prefix_bloom[bit >> 5] >> (bit & 31u)) & 1u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kWinPer; j++) {
+                    if ((alive >> j) & 1u) {
+                        if (word[j]) { mlen[j]++; hh[j] = h2[j]; } else alive &= ~(1u << j);
+                    }
+                }
+            }
+            // furthest reach before each position: own earlier positions, earlier threads, earlier windows
+            uint32_t own = 0, pre[kWinPer];
+#pragma unroll
+            for (int j = 0; j < kWinPer; j++) {
+                pre[j] = own;
+                const uint32_t p = p0 + (uint32_t)j;
+                if (p < n) { const uint32_t r = p + mlen[j]; own = r > own ? r : own; }
+            }
+            uint32_t inc = own;   // inclusive max-scan over the threads
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if (lane >= (uint32_t)d) inc = o > inc ? o : inc;
+            }
+            if (lane == 63) P.tmp[wave] = inc;
+            __syncthreads();
+            uint32_t before = carry > w0 ? carry - w0 : 0u, all = before;
+            for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+                const uint32_t x = P.tmp[w2];
+                if (w2 < wave) before = x > before ? x : before;
+                all = x > all ? x : all;
+            }
+            {
+                const uint32_t ex = __shfl_up(inc, 1, 64);
+                if (lane > 0) before = ex > before ? ex : before;
+            }
+            uint32_t cuts = 0;
+#pragma unroll
+            for (int j = 0; j < kWinPer; j++) {
+                const uint32_t p = p0 + (uint32_t)j;
+                const uint32_t pm = pre[j] > before ? pre[j] : before;
+                if (p < n && pm <= p) cuts |= 1u << j;
+            }
+            P.cutw[tid] = (uint16_t)cuts;
+            uint32_t k_total;
+            const uint32_t kbase = block_escan<kSlowThreads / 64>((uint32_t)__popc(cuts), P.tmp + 8, &k_total);
+            {
+                uint32_t k = kbase, c = cuts;
+                while (c) { const int j = __builtin_ctz(c); c &= c - 1; P.pl[k++] = (uint16_t)(p0 + (uint32_t)j); }
+            }
+            const bool at_end = w0 + n == L;
+            if (tid == 0 && at_end) P.pl[k_total] = (uint16_t)n;
+            __syncthreads();
+            // a piece that began in an earlier window (longer than a window): it ends at this window's first cut
+            if (open_start < w0) {
+                if (k_total > 0) {
+                    const uint32_t c0 = P.pl[0];
+                    rounds_piece(T, W, S, sp, open_start, w0 + c0 - open_start, false, img, tmp, tmp64, segtmp, lvars, xb);
+                    open_start = w0 + c0;
+                } else if (at_end) {
+                    rounds_piece(T, W, S, sp, open_start, L - open_start, open_start == 0, img, tmp, tmp64, segtmp, lvars, xb);
+                    break;
+                } else {
+                    carry = w0 + all;
+                    w0 += n;
+                    continue;
+                }
+            }
+            // complete pieces of this window: [pl[i], pl[i + 1]), i < n_complete
+            const uint32_t n_complete = at_end ? k_total : k_total - 1u;   // (k_total >= 1 here)
+            const bool whole_single = at_end && k_total == 1 && w0 == 0 && open_start == 0;   // the pre-token is one piece
+#pragma unroll 1
+            for (uint32_t i0 = 0; i0 < n_complete; i0 += kSlowThreads) {
+                const uint32_t i = i0 + (uint32_t)tid;
+                const bool have = i < n_complete;
+                const uint32_t s = have ? P.pl[i] : 0u;
+                const uint32_t plen = have ? (uint32_t)P.pl[i + 1] - s : 0u;
+                const uint64_t q = (uint64_t)w0 + s;
+                const bool is_long = have && (plen > (uint32_t)kLaneMax || whole_single);
+                if (have && plen == 1 && !is_long) img[q] = byte_tok[P.wb[s]];
+                __syncthreads();   // the union is free (a rounds_piece of the previous chunk is over)
+                // -- 2 .. 16 symbols: a 16-element slot per lane
+                {
+                    const bool act = have && !is_long && plen >= 2 && plen <= 16;
+                    uint32_t* sy = sy_a + tid * 17;
+                    uint32_t* pq = pq_a + tid * 17;
+                    if (act) {
+                        uint32_t bb[16], pp[15];
+#pragma unroll
+                        for (int j = 0; j < 16; j++) bb[j] = P.wb[s + (uint32_t)j];
+#pragma unroll
+                        for (int j = 0; j < 15; j++) pp[j] = (uint32_t)(j + 1) < plen ? T.bytepair[(bb[j] << 8) | bb[j + 1]] : kNoPrio;
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const uint32_t nxt = (uint32_t)(j + 1) < plen ? (uint32_t)(j + 1) : kNone, prv = j ? (uint32_t)(j - 1) : kNone;
+                            sy[j] = (uint32_t)byte_tok[bb[j]] | (nxt << 17) | (prv << 24);
+                            pq[j] = (j < 15 && pp[j < 15 ? j : 0] != kNoPrio && (uint32_t)j < plen) ? (pp[j < 15 ? j : 0] << 7) | (uint32_t)j : 0xFFFFFFFFu;
+                        }
+                        lane_merge<16>(T, sy, pq);
+                        slot_to_image(sy, img, q, plen);
+                    }
+                }
+                // -- 17 .. kLaneMax symbols: groups of 64 lanes, 64-element slots of the same arena
+                const bool is_mid = have && !is_long && plen > 16;
+                const int n_mid = __syncthreads_count(is_mid);
+                if (n_mid) {
+                    uint32_t tot;
+                    const uint32_t ord = block_escan<kSlowThreads / 64>(is_mid ? 1u : 0u, P.tmp, &tot);
+#pragma unroll 1
+                    for (uint32_t g = 0; g * 64u < (uint32_t)n_mid; g++) {
+                        const bool act = is_mid && ord / 64u == g;
+                        uint32_t* sy = sy_a + (ord % 64u) * 65u;
+                        uint32_t* pq = pq_a + (ord % 64u) * 65u;
+                        if (act) {
+                            uint32_t prev = P.wb[s];
+                            for (uint32_t j = 0; j < 64; j++) {
+                                if (j < plen) {
+                                    const uint32_t cur = j + 1 < plen ? (uint32_t)P.wb[s + j + 1] : 0u;
+                                    const uint32_t pr = j + 1 < plen ? T.bytepair[(prev << 8) | cur] : kNoPrio;
+                                    sy[j] = (uint32_t)byte_tok[prev] | ((j + 1 < plen ? j + 1 : kNone) << 17) | ((j ? j - 1 : kNone) << 24);
+                                    pq[j] = pr != kNoPrio ? (pr << 7) | j : 0xFFFFFFFFu;
+                                    prev = cur;
+                                } else {
+                                    pq[j] = 0xFFFFFFFFu;
+                                }
+                            }
+                            lane_merge<64>(T, sy, pq);
+                            slot_to_image(sy, img, q, plen);
+                        }
+                        __syncthreads();
+                    }
+                }
+                // -- longer pieces of this chunk, one after the other by the whole workgroup
+                if (tid < 4) P.vars[tid] = 0;
+                __syncthreads();
+                {
+                    const unsigned long long lm = __ballot(is_long);
+                    if (lane == 0) { P.tmp[wave * 2] = (uint32_t)lm; P.tmp[wave * 2 + 1] = (uint32_t)(lm >> 32); }
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+                    unsigned long long lm = (unsigned long long)P.tmp[w2 * 2] | ((unsigned long long)P.tmp[w2 * 2 + 1] << 32);
+                    while (lm) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(lm);
+                        lm &= lm - 1ull;
+                        const uint32_t pi = i0 + w2 * 64u + b;
+                        const uint32_t ps = P.pl[pi], pe = P.pl[pi + 1];
+                        rounds_piece(T, W, S, sp, (uint64_t)w0 + ps, pe - ps, whole_single, img, tmp, tmp64, segtmp, lvars, xb);
+                    }
+                }
+            }
+            if (at_end) break;
+            const uint32_t last = P.pl[k_total - 1u];   // start of the piece still open at the end of the window
+            if (last > 0) { open_start = w0 + last; w0 = open_start; carry = w0; }   // look at it again from its start
+            else { carry = w0 + all; w0 += n; }                                      // it fills the window: go on
         }
         __syncthreads();
+        // ---- 4. compact the image in place (16 slots per thread and step; the write cursor never passes the reads)
+        uint32_t n_out = 0;
+#pragma unroll 1
+        for (uint32_t base = 0; base < L; base += (uint32_t)kWin) {
+            int32_t v[kWinPer];
+            const uint32_t p0 = base + (uint32_t)tid * (uint32_t)kWinPer;
+            uint32_t live = 0;
+#pragma unroll
+            for (int j = 0; j < kWinPer; j++) {
+                v[j] = p0 + (uint32_t)j < L ? img[p0 + (uint32_t)j] : -1;
+                if (v[j] >= 0) live++;
+            }
+            uint32_t tot;
+            const uint32_t ex = block_escan<kSlowThreads / 64>(live, P.tmp, &tot);   // (barriers: every read is done before a write)
+            uint32_t o = n_out + ex;
+#pragma unroll
+            for (int j = 0; j < kWinPer; j++)
+                if (v[j] >= 0) img[o++] = v[j];
+            n_out += tot;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            W.slow[ei].count = n_out;
+            W.slow[ei].pool_off = (unsigned long long)kMissShards * W.mpool_shard_cap + (unsigned long long)lvars[4];
+            if (n_out > 1) atomicAdd(&W.tile_extra[W.slow[ei].tile], n_out - 1);
+        }
     }
 }
 

@@ -309,6 +309,29 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
         if (T.vocab_log2 > 24) { T.error = "vocabulary table placement failed"; return false; }
     }
 
+    // ---- prefix tables for the cut points of long pre-tokens (l3_common.h): every prefix of 2 and more bytes of every
+    //      entry of the base vocabulary (special-token names are no BPE symbols)
+    T.prefix2.assign(kPrefix2Words, 0);
+    {
+        size_t n_long = 0;
+        for (int id = 0; id < n_base; id++) { uint32_t l = T.tok_off[id + 1] - T.tok_off[id]; if (l > 2) n_long += l - 2; }
+        T.bloom_log2 = 20;
+        while ((1ull << T.bloom_log2) < n_long * 24 && T.bloom_log2 < 26) T.bloom_log2++;   // <= 1/24 of the bits set: ~4 % false positives
+        T.prefix_bloom.assign((size_t)1 << (T.bloom_log2 - 5), 0);
+        for (int id = 0; id < n_base; id++) {
+            const uint8_t* b = T.tok_bytes.data() + T.tok_off[id];
+            const uint32_t l = T.tok_off[id + 1] - T.tok_off[id];
+            if (l < 2) continue;
+            T.prefix2[((uint32_t)b[0] << 3) | (b[1] >> 5)] |= 1u << (b[1] & 31u);
+            uint32_t h = cut_hash2(b[0], b[1]);
+            for (uint32_t k = 2; k < l; k++) {
+                h = cut_hash_add(h, b[k]);
+                const uint32_t bit = cut_hash_bit(h, T.bloom_log2);
+                T.prefix_bloom[bit >> 5] |= 1u << (bit & 31u);
+            }
+        }
+    }
+
     build_class_tables(T);
     return true;
 }
