@@ -66,7 +66,7 @@ struct DevBuf {
 };
 
 // Capacities of the lists a call appends to (entries, not bytes; scratch_cap in bytes).
-struct Caps { uint64_t slow_cap, miss_shard_cap, mpool_shard_cap, pool_cap, scratch_cap; };
+struct Caps { uint64_t slow_cap, miss_shard_cap, mpool_shard_cap, pool_cap, scratch_cap, win_cap; };
 
 }  // namespace
 
@@ -83,7 +83,7 @@ struct l3_ctx {
     hipEvent_t ev_clear = nullptr;
     DevBuf w_arena, w_status;         // the per-call workspace (one block, carve_workspace) and the status word
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
-    Caps caps{0, 0, 0, 0, 0};         // list capacities inside the workspace, grow-only
+    Caps caps{0, 0, 0, 0, 0, 0};         // list capacities inside the workspace, grow-only
     unsigned char* na_scratch = nullptr;  // this GPU's copy of the file-scope array `scratch` (hipGetSymbolAddress at l3_create)
     Status* h_status = nullptr;          // pinned
     unsigned long long* h_total = nullptr;  // pinned
@@ -98,7 +98,7 @@ struct l3_ctx {
     float last_ms[kEvCount] = {};
     double sum_ms[kEvCount] = {};     // over the profiled calls since profiling was switched on
     uint64_t sum_calls = 0;
-    uint64_t counters[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::unordered_map<std::string, int> special_by_name;
     std::mutex mu;
     std::string err;
@@ -170,6 +170,7 @@ size_t carve_workspace(uint8_t* base, uint64_t n_bytes, uint64_t n_docs, const C
     W.tile_items = reinterpret_cast<uint32_t*>(take(n_tiles * 4));
     W.tile_extra = reinterpret_cast<uint32_t*>(take(n_tiles * 8));  // tile_extra + tile_digits
     W.tile_digits = base ? W.tile_extra + n_tiles : nullptr;
+    W.tile_first = reinterpret_cast<uint32_t*>(take(n_tiles * 4));
     W.tile_base = reinterpret_cast<uint64_t*>(take((n_tiles / 1024 + 2) * 8));
     W.tile_rec = reinterpret_cast<TileRec*>(take(n_tiles * sizeof(TileRec)));
     W.tile_flag = reinterpret_cast<uint32_t*>(take(n_tiles * 4));
@@ -180,6 +181,9 @@ size_t carve_workspace(uint8_t* base, uint64_t n_bytes, uint64_t n_docs, const C
     W.miss_res = reinterpret_cast<uint64_t*>(take(K.miss_shard_cap * kMissShards * sizeof(uint64_t)));
     W.pool = reinterpret_cast<int32_t*>(take((K.mpool_shard_cap * kMissShards + K.pool_cap) * sizeof(int32_t)));
     W.scratch = take(K.scratch_cap);
+    W.win = reinterpret_cast<WinItem*>(take(K.win_cap * sizeof(WinItem)));
+    W.win_live = reinterpret_cast<uint32_t*>(take(K.win_cap * 4));
+    W.win_cap = K.win_cap;
     W.status = status;
     W.slow_cap = K.slow_cap;
     W.miss_shard_cap = K.miss_shard_cap;
@@ -197,6 +201,7 @@ Caps initial_caps(uint64_t n_bytes) {
     K.pool_cap = n_bytes / 8 + 4096;
     K.mpool_shard_cap = n_bytes / 16 / kMissShards + 1024;
     K.scratch_cap = 16ull << 20;
+    K.win_cap = n_bytes / 8192 + 1024;
     return K;
 }
 
@@ -219,6 +224,7 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     if (K.pool_cap < K0.pool_cap) K.pool_cap = K0.pool_cap;
     if (K.mpool_shard_cap < K0.mpool_shard_cap) K.mpool_shard_cap = K0.mpool_shard_cap;
     if (K.scratch_cap < K0.scratch_cap) K.scratch_cap = K0.scratch_cap;
+    if (K.win_cap < K0.win_cap) K.win_cap = K0.win_cap;
     if (!caps_addressable(K)) {
         c->err = "batch too large for one call (deferred pre-token lists exceed 2^30 entries): split it";
         return L3_E_INVALID_ARG;
@@ -274,7 +280,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false));
         HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
-        if (c->h_status->generic_tiles && !(c->h_status->flags & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch | kOvfOut))) {
+        if (c->h_status->generic_tiles && !(c->h_status->flags & (kFatalFlags | kRetryFlags | kOvfOut))) {
             // tiles with empty documents or token floods: the generic scatter, launched only when the fast one asks
             HIPCHK(c, launch_emit_generic(W, A, stream));
             HIPCHK(c, hipStreamSynchronize(stream));
@@ -285,7 +291,12 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
             c->err = "doc_off must start at 0, be ascending and end at n_bytes";
             return L3_E_INVALID_ARG;
         }
+        if (st.flags & kTooLong) {
+            c->err = "a single pre-token of 2 GiB or more is not supported";
+            return L3_E_INVALID_ARG;
+        }
         bool grow = false;
+        if (st.flags & kOvfWin) { c->caps.win_cap = (uint64_t)st.slow_q.count + st.slow_q.count / 4 + 1024; grow = true; }
         if (st.flags & kOvfSlow) { c->caps.slow_cap = (uint64_t)st.slow_count + st.slow_count / 4 + 1024; grow = true; }
         uint64_t miss_total = 0, miss_max = 0, mpool_max = 0, mpool_total = 0;
         for (int i = 0; i < kMissShards; i++) {
@@ -323,6 +334,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         c->counters[2] = st.pool_used + mpool_total;
         c->counters[3] = st.scratch_used;
         c->counters[5] = miss_total;
+        c->counters[6] = st.slow_q.count;
         *n_tok = st.total_tokens;
         if (W_out) *W_out = W;
         return (st.flags & kOvfOut) ? L3_E_OUTPUT_CAP : L3_OK;
@@ -503,7 +515,11 @@ int l3_encode_batch_device_noalloc(l3_ctx* c, const uint8_t* d_text, uint64_t n_
         c->err = "doc_off must start at 0, be ascending and end at n_bytes";
         return L3_E_INVALID_ARG;
     }
-    if (st.flags & (kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) {
+    if (st.flags & kTooLong) {
+        c->err = "a single pre-token of 2 GiB or more is not supported";
+        return L3_E_INVALID_ARG;
+    }
+    if (st.flags & kRetryFlags) {
         c->err = "batch needs more workspace than the static array of l3_encode_batch_device_noalloc holds (unusually many "
                  "deferred pre-tokens): use l3_encode_batch_device";
         return L3_E_SCRATCH;
@@ -572,7 +588,7 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
     }
     uint64_t total = 0, base[9];
     bool overflow = false;
-    uint64_t sum_counters[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t sum_counters[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < S; k++) {
         const uint64_t nd = d_lo[k + 1] - d_lo[k];
         const uint64_t b0 = doc_off[d_lo[k]], nb = doc_off[d_lo[k + 1]] - b0;
@@ -598,7 +614,7 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
             if (rc == L3_OK && hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "hipStreamSynchronize failed"; rc = L3_E_HIP; }
         }
         if (rc) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamSynchronize(c->stream_out); return rc; }
-        for (int i = 0; i < 6; i++) sum_counters[i] += c->counters[i];
+        for (int i = 0; i < 7; i++) sum_counters[i] += c->counters[i];
         total += tk;
         if (total > out_cap) overflow = true;
         HIPCHK(c, hipMemcpyAsync(out_off + d_lo[k], oo.p, nd * 8, hipMemcpyDeviceToHost, c->stream_out));
@@ -610,7 +626,7 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
     for (int k = 1; k < S; k++)
         if (base[k]) for (uint64_t d = d_lo[k]; d < d_lo[k + 1]; d++) out_off[d] += base[k];
     out_off[n_docs] = total;
-    for (int i = 0; i < 6; i++) c->counters[i] = sum_counters[i];
+    for (int i = 0; i < 7; i++) c->counters[i] = sum_counters[i];
     *n_tok = total;
     if (overflow) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
     return L3_OK;
@@ -800,7 +816,7 @@ int l3_timing_totals(l3_ctx* c, double* ms, int cap, uint64_t* calls) {
 int l3_last_counters(l3_ctx* c, uint64_t* out, int cap) {
     if (!c || !out) return L3_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
-    int n = cap < 6 ? cap : 6;
+    int n = cap < 7 ? cap : 7;
     for (int i = 0; i < n; i++) out[i] = c->counters[i];
     return n;
 }

@@ -31,6 +31,11 @@ constexpr int kSlowLds = L3_SLOW_LDS;    // symbols of a slow pre-token merged i
 #endif
 constexpr int kMidBytes = L3_MID_BYTES;  // slow entries of known length up to this are merged by ONE wave each
 constexpr int kMidSyms = L3_SLOW_LDS / 4; // ... in LDS when they have at most this many symbols (four waves share the arena)
+#ifndef L3_WIN
+#define L3_WIN 1920
+#endif
+constexpr int kWin = L3_WIN;             // symbols of a long pre-token one window item owns
+constexpr int kWinBack = 128;            // ... and looks back (a vocabulary entry has at most kMaxTokenBytes bytes)
 
 // A stream item is a token id (>= 0) or the placeholder -2 - e of a deferred pre-token: e < kSlowBase
 // is an index into Workspace::miss_in / miss_res (short: merged one lane each by merge_kernel), e >= kSlowBase is
@@ -38,18 +43,23 @@ constexpr int kMidSyms = L3_SLOW_LDS / 4; // ... in LDS when they have at most t
 constexpr uint32_t kNoSpecial = 4;  // EncodeArgs::flags: special-token names are ordinary text (bare pre-tokenizer)
 constexpr int32_t kDead = -1;
 constexpr uint32_t kSlowBase = 1u << 30;
+constexpr uint32_t kNoFirst = 0x7FFFFFFFu, kFirstInv = 0x80000000u;   // Workspace::tile_first
 
 // A pre-token the tile kernel does not finish itself: it contains invalid UTF-8 (its symbols are
 // not its bytes), is longer than kLaneMax without being a vocabulary entry, or ends past the halo.
 struct SlowEntry {
     uint64_t start;      // global byte offset of its first byte
-    uint64_t scan_from;  // len == 0: first position the tile kernel could not decide
-    uint32_t len;        // source bytes, 0 = unknown (ends beyond the tile's look-ahead)
+    uint64_t win0;       // written by the preparation pass: index of its first window item (Workspace::win); bit 63
+                         // (kEntrySequential): it holds invalid UTF-8, ONE item works through all its windows
+    uint32_t len;        // source bytes, 0 = unknown (ends beyond the tile's look-ahead; the preparation pass fills it in)
     uint32_t tile;       // owning tile
-    uint32_t count;      // tokens produced (written by the slow kernel)
-    uint32_t pad;        // written by mid_kernel: see Status::slow_q
-    uint64_t pool_off;   // first token in the slow pool (written by the slow kernel)
+    uint32_t count;      // in (tile kernel): 1 = its bytes are known to be valid UTF-8; out: tokens produced
+    uint32_t pad;
+    uint64_t pool_off;   // first token in the slow pool
 };
+constexpr uint64_t kEntrySequential = 1ull << 63;
+// A long pre-token is worked on in windows of kWin symbols, one work item each (slow_kernel).
+struct WinItem { uint32_t entry, k; };
 
 // status word written by the kernels (device memory, zeroed per call)
 enum : uint32_t {
@@ -59,7 +69,11 @@ enum : uint32_t {
     kBadOffsets = 8,   // doc_off is not ascending / does not start at 0 / does not end at n_bytes
     kOvfScratch = 16,  // giant pre-token scratch too small
     kOvfMiss = 32,     // more short deferred pre-tokens than miss_cap
+    kOvfWin = 64,      // more window items than win_cap
+    kTooLong = 128,    // a single pre-token of 2 GiB or more
 };
+constexpr uint32_t kRetryFlags = kOvfSlow | kOvfPool | kOvfScratch | kOvfMiss | kOvfWin;   // the host grows a list and runs the batch again
+constexpr uint32_t kFatalFlags = kBadOffsets | kTooLong;
 struct Status {
     uint32_t slow_count;        // entries appended so far (may exceed capacity: overflow)
     uint32_t flags;             // kOvf* / kBadOffsets
@@ -75,10 +89,10 @@ struct Status {
         uint32_t pad;
         unsigned long long pool_used;   // tokens reserved in the shard's part of the pool (may exceed mpool_shard_cap)
     } shard[64];
-    // Work queues over the slow list, on cache lines of their own.  mid_q: mid_kernel's waves take the list a few
-    // entries at a time, do the entries of known, moderate length themselves and note the others in SlowEntry::pad
-    // (pad of entry k = index of the k-th such entry, slow_q.count of them); slow_q: slow_kernel's workgroups take
-    // those one at a time.
+    // Work queues, on cache lines of their own.  mid_q: over the slow list; the waves of the pass inside merge_kernel's
+    // launch take it a few entries at a time, do the entries of known, moderate length themselves and prepare the others
+    // (end, room in the pool, window items).  slow_q: over the window items (count of them); slow_kernel's workgroups
+    // take those one at a time.
     struct alignas(128) Queue { uint32_t next, count; } slow_q, mid_q;
 };
 constexpr int kMissShards = 64;
@@ -108,6 +122,8 @@ struct Workspace {
     uint32_t* tile_extra;   // [n_tiles] sum of (tokens - 1) over the tile's deferred pre-tokens (atomic adds)
     uint32_t* tile_digits;  // [n_tiles] 0, or 1 + the number of decimal-digit runes right before the tile start (a tile that had to
                             // count them leaves the figure for the tiles after it: see digits_before_global)
+    uint32_t* tile_first;   // [n_tiles] offset (from the tile start) of the first pre-token start the tile owns, kNoFirst: none;
+                            // bit 31 (kFirstInv): among the bytes the tile owns one is not valid UTF-8
     uint64_t* tile_base;    // [ceil(n_tiles / 1024)] exclusive scan of the token totals of blocks of 1024 tiles
     TileRec* tile_rec;      // [n_tiles] what the emit kernels need to know about a tile, in one 32-byte load
     uint32_t* tile_flag;    // [n_tiles] 1 = the fast emit kernel left the tile to the generic one
@@ -119,8 +135,10 @@ struct Workspace {
     int32_t* pool;          // [kMissShards * mpool_shard_cap + pool_cap]: results of more than kMissInline tokens of the
                             // merge kernel, one part per shard, then the tokens of the slow pre-tokens
     uint8_t* scratch;       // [scratch_cap] symbol arrays of pre-tokens too long for LDS
+    WinItem* win;           // [win_cap] window items of the long pre-tokens
+    uint32_t* win_live;     // [win_cap] tokens in the image slots of each window's range
     Status* status;
-    uint64_t slow_cap, miss_shard_cap, mpool_shard_cap, pool_cap, scratch_cap;
+    uint64_t slow_cap, miss_shard_cap, mpool_shard_cap, pool_cap, scratch_cap, win_cap;
 };
 
 struct EncodeArgs {
@@ -136,7 +154,7 @@ struct EncodeArgs {
                               // 2 = special-token start, 0 otherwise
 };
 
-inline uint64_t num_tiles(uint64_t n_bytes) { return n_bytes == 0 ? 1 : (n_bytes + kTile - 1) / kTile; }
+__host__ __device__ inline uint64_t num_tiles(uint64_t n_bytes) { return n_bytes == 0 ? 1 : (n_bytes + kTile - 1) / kTile; }
 
 enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvEmit, kEvCount };
 

@@ -302,7 +302,7 @@ struct TileLds {
 };
 constexpr int kListPer = 16;
 static_assert(kListPer * kTileThreads >= kTile && 64 % kListPer == 0 && kBack % kListPer == 0, "list compaction geometry");
-enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NSLOW, TV_SLOW0, TV_NRARE, TV_ANYINV, TV_LASTE, TV_COUNT = 8 };
+enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NSLOW, TV_SLOW0, TV_NRARE, TV_ANYINV, TV_LASTE, TV_OWNINV, TV_COUNT = 12 };
 
 struct TileSrc {  // byte source over the tile's LDS image, LOCAL coordinates [0, n)
     const TileLds* R;
@@ -365,7 +365,8 @@ __device__ __forceinline__ Seg wave_seg_escan(Seg v) {
 // Start-of-pre-token bits of the whole region, by the lanes of ONE wave (lane w = mask word w).
 // `edge_digits`: number of Nd runes immediately before the tile start when a digit run fills the
 // whole look-behind halo (only read when `use_edge`).  Writes bm[B_ST], bm[B_N], bm[B_CONTN], wpre[];
-// returns flags: bit0 a digit run reaches the region start (edge count needed), bit1 multi-byte digits.
+// returns flags: bit0 a digit run reaches the region start (edge count needed), bit1 multi-byte digits, bit2 the tile's
+// own bytes hold invalid UTF-8.
 __device__ __noinline__ uint32_t compute_starts(TileLds& R, int n, int own_lo, int own_hi, int eval_hi, bool region_at_text_start,
                                                 bool use_edge, uint32_t edge_digits, int* n_pre_out) {
     const int w = lane_id();
@@ -516,6 +517,16 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int n, int own_lo, i
             if (own_lo > lo) own &= ~0ull << (own_lo - lo);
             if (own_hi < lo + 64) own &= (1ull << (own_hi - lo)) - 1ull;
         }
+    }
+    {   // invalid UTF-8 among the bytes the tile OWNS (the halos cut characters in two: their stray bytes do not count)
+        u64 inv = L3_LD(B_INV);
+        const int lo = w * 64;
+        if (own_lo >= lo + 64 || own_hi <= lo) inv = 0;
+        else {
+            if (own_lo > lo) inv &= ~0ull << (own_lo - lo);
+            if (own_hi < lo + 64) inv &= (1ull << (own_hi - lo)) - 1ull;
+        }
+        if (__ballot(inv != 0) != 0) flags |= 4u;
     }
     uint32_t cnt = (uint32_t)__popcll(own);
     uint32_t inc = wave_iscan(cnt);
@@ -683,6 +694,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             vars[TV_NPRE] = n_pre;
             vars[TV_MB] = (fl & 2u) ? 1 : 0;
             vars[TV_NEED] = ((fl & 1u) || ((fl & 2u) && g_lo > 0)) ? 1 : 0;
+            vars[TV_OWNINV] = (fl & 4u) ? 1 : 0;
         }
     }
     __syncthreads();
@@ -913,6 +925,9 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         nm_r = (uint32_t)vars[TV_NSLOW];
         m0_r = nm_r ? atomicAdd(&W.status->slow_count, nm_r) : 0u;
         W.tile_items[tile] = n_pre;
+        // first own pre-token start (relative to the tile) and "the bytes it owns hold invalid UTF-8": how the slow kernel finds the
+        // end of a pre-token that runs past this tile's look-ahead, and whether its symbols can differ from its bytes
+        W.tile_first[tile] = (n_pre ? (uint32_t)(R.list[0] - own_lo) : kNoFirst) | (vars[TV_OWNINV] ? kFirstInv : 0u);
     }
     // -- stream index of the first item of every document that starts in this tile
     {
@@ -962,10 +977,11 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                     if (ei < W.slow_cap) {
                         SlowEntry se;
                         se.start = g_lo + (uint64_t)s;
-                        se.scan_from = g_lo + (uint64_t)eval_hi;
+                        se.win0 = 0;
                         se.len = e < 0 ? 0u : (uint32_t)(e - s);
                         se.tile = (uint32_t)tile;
-                        se.count = 0; se.pad = 0; se.pool_off = 0;
+                        se.count = (e >= 0 && !any_bit_in(R.bm[B_INV], s, e)) ? 1u : 0u;   // in: 1 = known to be valid UTF-8
+                        se.pad = 0; se.pool_off = 0;
                         W.slow[ei] = se;
                     }
                     ei += kSlowBase;
@@ -1008,10 +1024,11 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                     if (ei < W.slow_cap) {
                         SlowEntry se;
                         se.start = g_lo + (uint64_t)s;
-                        se.scan_from = g_lo + (uint64_t)eval_hi;
+                        se.win0 = 0;
                         se.len = e < 0 ? 0u : (uint32_t)(e - s);
                         se.tile = (uint32_t)tile;
-                        se.count = 0; se.pad = 0; se.pool_off = 0;
+                        se.count = (e >= 0 && !any_bit_in(R.bm[B_INV], s, e)) ? 1u : 0u;   // in: 1 = known to be valid UTF-8
+                        se.pad = 0; se.pool_off = 0;
                         W.slow[ei] = se;
                     }
                     ei += kSlowBase;
@@ -1543,6 +1560,7 @@ __device__ void mid_entry(const Tables& T, const Workspace& W, const EncodeArgs&
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint64_t start = W.slow[ei].start;
     const uint32_t len = W.slow[ei].len;
+    const bool valid = W.slow[ei].count == 1u;   // the tile kernel saw no invalid byte in it: its symbols are its bytes
     GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
     group_sync<true>();  // the arena may still be read by this wave's previous entry
     int32_t *sa = M.sA, *sb = M.sB;
@@ -1567,7 +1585,7 @@ __device__ void mid_entry(const Tables& T, const Workspace& W, const EncodeArgs&
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t q = base + lane;
         const bool in = q < len;
-        const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
+        const bool inv = in && !valid && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
         const unsigned long long mi = __ballot(in), mv = __ballot(inv);
         const uint32_t pos = o + (uint32_t)__popcll(mi & lt) + 2u * (uint32_t)__popcll(mv & lt);
         if (inv) {
@@ -1607,6 +1625,63 @@ __device__ void mid_entry(const Tables& T, const Workspace& W, const EncodeArgs&
     for (uint32_t i = lane; i < n_out; i += 64) dst[i] = sa[i] & kIdMask;
 }
 
+// Preparation of a long slow entry for slow_kernel, by the calling wave: where it ends, whether its symbols are its
+// bytes, room for its tokens in the slow pool, its window items.
+//   End (state_machine.go:53-79: at the next pre-token start): its tile saw none up to the end of its look-ahead, which
+//   lies in the next tile; every tile decides all the positions it owns, so the end is the first pre-token start owned
+//   by a later tile (document ends and special tokens are starts), or the end of the text.
+//   Room: an IMAGE of the pre-token (one slot per symbol, see slow_kernel) behind the place of its final tokens.
+__device__ void prep_entry(const Workspace& W, const EncodeArgs& A, uint32_t e) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint64_t start = W.slow[e].start;
+    uint64_t len = W.slow[e].len;
+    bool valid = W.slow[e].count == 1u;
+    if (len == 0) {
+        const uint64_t n_tiles = num_tiles(A.n_bytes);
+        const uint64_t tile0 = W.slow[e].tile;
+        bool inv = (W.tile_first[tile0] & kFirstInv) != 0;
+        uint64_t end = A.n_bytes;
+        for (uint64_t t0 = tile0 + 1; t0 < n_tiles; t0 += 64) {
+            const uint64_t t = t0 + lane;
+            const uint32_t f = t < n_tiles ? W.tile_first[t] : kNoFirst;
+            const unsigned long long hm = __ballot((f & ~kFirstInv) != kNoFirst), im = __ballot((f & kFirstInv) != 0);
+            if (hm) {
+                const int b = __builtin_ctzll(hm);
+                if (im & ((2ull << b) - 1ull)) inv = true;
+                end = (t0 + (uint64_t)b) * (uint64_t)kTile + (uint64_t)(__shfl(f, b, 64) & ~kFirstInv);
+                break;
+            }
+            if (im) inv = true;
+        }
+        valid = !inv;
+        len = end - start;
+    }
+    if (len >= (1ull << 31)) {
+        if (lane == 0) { atomicOr(&W.status->flags, kTooLong); W.slow[e].len = 0; W.slow[e].count = 0; W.slow[e].win0 = ~0ull; }
+        return;
+    }
+    const uint64_t slots = valid ? len : 3ull * len;                 // symbols (an invalid byte is three: EF BF BD), at most
+    const uint32_t n_win = (uint32_t)((slots + (uint64_t)kWin - 1) / (uint64_t)kWin);
+    long long poff = -1, wbase = -1;
+    if (lane == 0) {
+        const unsigned long long off = atomicAdd(&W.status->pool_used, 2ull * slots);
+        if (off + 2ull * slots <= W.pool_cap) poff = (long long)off; else atomicOr(&W.status->flags, kOvfPool);
+        const uint32_t wb = atomicAdd(&W.status->slow_q.count, n_win);
+        if ((uint64_t)wb + n_win <= W.win_cap) wbase = (long long)wb; else atomicOr(&W.status->flags, kOvfWin);
+        W.slow[e].len = (uint32_t)len;
+        W.slow[e].count = 0;
+        W.slow[e].win0 = (uint64_t)(wbase < 0 ? 0 : wbase) | (valid ? 0ull : kEntrySequential);
+        W.slow[e].pool_off = (unsigned long long)kMissShards * W.mpool_shard_cap + (unsigned long long)(poff < 0 ? 0 : poff);
+    }
+    poff = __shfl(poff, 0, 64);
+    wbase = __shfl(wbase, 0, 64);
+    if (poff < 0 || wbase < 0) return;   // the host grows the lists and runs the batch again
+    for (uint32_t k = lane; k < n_win; k += 64) {
+        W.win[(uint64_t)wbase + k] = WinItem{e, k};
+        W.win_live[(uint64_t)wbase + k] = 0;
+    }
+}
+
 // Every wave on its own takes a few entries of the slow list at a time, handles those of known, moderate length and
 // notes the others for slow_kernel (Status::slow_q).  Room in the slow pool is reserved once per visit, one token
 // per symbol of the entries taken (a returning atomic per entry on the one counter queued up: 0.3 ms for 58 k entries).
@@ -1617,7 +1692,6 @@ __device__ void mid_pass(const Tables& T, const Workspace& W, const EncodeArgs& 
     uint64_t n_slow = W.status->slow_count;
     if (n_slow > W.slow_cap) n_slow = W.slow_cap;
     const uint32_t lane = (uint32_t)lane_id();
-    const unsigned long long lt = (1ull << lane) - 1ull;
     MidLds& M = mid[wave_id()];
     // entries per visit to the counter: few enough that every wave of the grid gets some, at most kMidPop
     uint32_t pop = (uint32_t)(n_slow / ((uint64_t)n_blocks * (kSlowThreads / 64)));
@@ -1638,20 +1712,18 @@ __device__ void mid_pass(const Tables& T, const Workspace& W, const EncodeArgs& 
         const bool in = lane < pop && e < n_slow;
         const uint32_t len = in ? W.slow[e].len : 1u;
         const uint64_t start = in ? W.slow[e].start : 0ull;
+        const bool known_valid = in && W.slow[e].count == 1u;
         const bool big = in && (len == 0 || len > (uint32_t)kMidBytes);
         const unsigned long long bm = __ballot(big);
-        if (bm) {  // not for a single wave: noted for slow_kernel
-            uint32_t k0 = 0;
-            if (lane == 0) k0 = atomicAdd(&W.status->slow_q.count, (uint32_t)__popcll(bm));
-            k0 = __shfl(k0, 0, 64);
-            if (big) W.slow[k0 + (uint32_t)__popcll(bm & lt)].pad = e;
-        }
+        for (unsigned long long m = bm; m; m &= m - 1ull)   // not for a single wave: prepared for slow_kernel
+            prep_entry(W, A, e0 + (uint32_t)__builtin_ctzll(m));
         const unsigned long long mm = __ballot(in && !big);
         if (!mm) continue;
         uint32_t my_l = 0;  // lane b: symbols of entry e0 + b
         for (unsigned long long m = mm; m; m &= m - 1ull) {
             const int b = __builtin_ctzll(m);
-            const uint32_t lb = mid_symbols(T, A, __shfl(start, b, 64), __shfl(len, b, 64));
+            const uint32_t len_b = __shfl(len, b, 64);
+            const uint32_t lb = __shfl(known_valid ? 1 : 0, b, 64) ? len_b : mid_symbols(T, A, __shfl(start, b, 64), len_b);
             if (lane == (uint32_t)b) my_l = lb;
         }
         const uint32_t inc = wave_iscan(my_l);
@@ -1673,39 +1745,45 @@ __device__ void mid_pass(const Tables& T, const Workspace& W, const EncodeArgs& 
     }
 }
 
-// ---- long pre-tokens piece by piece ------------------------------------------------------------------------
+// ---- long pre-tokens piece by piece, window by window ---------------------------------------------------------
 // A long pre-token is cut at the positions no vocabulary entry can span (l3_common.h: prefix tables, reach, cuts); the
 // pieces are independent BPE problems.  Ideographs, byte soup and most non-Latin text fall into pieces of a few bytes,
 // which single lanes merge in LDS slots as merge_kernel does; only a piece of more than kLaneMax symbols (glued words,
-// one character repeated) still needs the round-based merge below.  Results go into an IMAGE of the pre-token in the slow
-// pool -- one int32 slot per symbol, piece p's tokens at the slots of its first symbols, -1 in the others --, which no
-// piece shares with another (so pieces can be done in any order), and the image is compacted in place at the end.
-constexpr int kWin = 4096;                       // symbols examined per window: 16 consecutive ones per thread
-constexpr int kWinPer = kWin / kSlowThreads;
-constexpr int kWinAhead = kMaxTokenBytes;        // a match looks at most this far ahead
-static_assert(kWinPer == 16, "cut masks are 16 bits per thread");
+// one character repeated) still needs the round-based merge.
+// Work items are WINDOWS of kWin symbols (prep_entry made them): an item decides the cuts inside its window -- a match
+// is at most kMaxTokenBytes long, so the reaches of the kWinBack symbols in front of the window are all it needs from
+// outside -- and handles the pieces that START in it, wherever they end.  Results go into an IMAGE of the pre-token in
+// the slow pool: one int32 slot per symbol, a piece's tokens in the slots of its first symbols, -1 in its others.  No
+// two pieces share a slot, so windows and pieces can be done in any order by any workgroup; win_live counts the tokens
+// in each window's slots, and finish_windows() (in the launch of block_totals_kernel) moves them to their final place.
+constexpr int kWinExam = kWin + kWinBack;                 // positions whose match length a window item computes
+constexpr int kWinPer = kWinExam / kSlowThreads;          // ... consecutive ones per thread
+constexpr int kWinAhead = kMaxTokenBytes;                 // a match looks at most this far ahead
+static_assert(kWinPer * kSlowThreads == kWinExam && kWinPer <= 16 && kWinBack >= kMaxTokenBytes, "window geometry");
+static_assert(kWin >= 2 * kLaneMax, "a lane piece reaches at most into the next window's slots");
 struct PieceLds {
-    uint8_t wb[kWin + kWinAhead + 16];           // the window's symbols (bytes) + look-ahead
-    uint16_t cutw[kSlowThreads];                 // cut bits of each thread's 16 positions
-    uint16_t pl[kWin + 2];                       // piece starts (window-local), ascending
+    uint8_t wraw[kWinExam + kWinAhead + 48];     // the window's symbols (bytes): look-behind, own, look-ahead; loaded in
+                                                 // aligned 16-byte pieces, so the first symbol sits at wraw[0 .. 15]
+    uint16_t pl[kWin + 2];                       // piece starts (window-local: index into wb), ascending
+    uint16_t ml[kWin];                           // indices (into pl) of the pieces of two and more symbols
     uint32_t tmp[16];
     uint32_t vars[8];
 };
 union SlowLds {
-    RegionLds R;                                 // finding the end of an open-ended pre-token
     MergeLds M;                                  // round-based merge of a long piece
     uint32_t arena[2 * kMergeArena];             // lane slots of the short pieces
 };
 
 // Round-based merge of the piece [q, q + n) of the symbol bytes `sp`, by the whole workgroup; `whole`: the piece is the
 // entire pre-token (then the whole-string probe of bpe.go:27-33 comes first).  Tokens go to img[q ..], -1 behind them.
-__device__ __noinline__ void rounds_piece(const Tables& T, const Workspace& W, SlowLds& S, const uint8_t* sp, uint64_t q, uint32_t n,
-                                          bool whole, int32_t* img, uint32_t* tmp, unsigned long long* tmp64, Seg* segtmp,
-                                          long long* lvars, uint8_t* xb) {
+// Returns the number of tokens (0 when the scratch is too small: the host grows it and runs the batch again).
+__device__ __noinline__ uint32_t rounds_piece(const Tables& T, const Workspace& W, SlowLds& S, const uint8_t* sp, uint64_t q, uint32_t n,
+                                              bool whole, int32_t* img, uint32_t* tmp, unsigned long long* tmp64, Seg* segtmp,
+                                              long long* lvars, uint8_t* xb) {
     const int tid = threadIdx.x;
     int32_t *sa, *sb;
     uint32_t *pa, *pb;
-    __syncthreads();   // the union is free: everybody is done with the lane slots / the region image
+    __syncthreads();   // the union is free: everybody is done with the lane slots
     if (n <= (uint32_t)kSlowLds) {
         sa = S.M.sA; sb = S.M.sB; pa = S.M.pA; pb = S.M.pB;
     } else {
@@ -1717,7 +1795,7 @@ __device__ __noinline__ void rounds_piece(const Tables& T, const Workspace& W, S
         }
         __syncthreads();
         const long long off = lvars[2];
-        if (off < 0) return;   // (uniform) the host grows the scratch and runs the batch again
+        if (off < 0) return 0;   // (uniform)
         uint8_t* base = W.scratch + off;
         sa = reinterpret_cast<int32_t*>(base);
         sb = sa + n;
@@ -1749,20 +1827,367 @@ __device__ __noinline__ void rounds_piece(const Tables& T, const Workspace& W, S
     }
     for (uint32_t i = (uint32_t)tid; i < n; i += kSlowThreads) img[q + i] = i < n_out ? (sa[i] & kIdMask) : -1;
     __syncthreads();
+    return n_out;
 }
 
-// Tokens of a finished lane slot to the image: piece [q, q + len)
-__device__ __forceinline__ void slot_to_image(const uint32_t* sy, int32_t* img, uint64_t q, uint32_t len) {
+// Tokens of a finished lane slot to the image: piece [q, q + len).  Returns their number.
+__device__ __forceinline__ uint32_t slot_to_image(const uint32_t* sy, int32_t* img, uint64_t q, uint32_t len) {
     uint32_t p = 0, k = 0;
     while (p != kNone) {
         const uint32_t w = sy[p];
         img[q + k++] = (int32_t)(w & 0x1FFFFu);
         p = (w >> 17) & 127u;
     }
+    const uint32_t cnt = k;
     for (; k < len; k++) img[q + k] = -1;
+    return cnt;
 }
 
-__global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace W, EncodeArgs A) {
+// Shared state of slow_kernel's workgroup (LDS), handed to window_work()
+struct SlowShared {
+    SlowLds* S;
+    PieceLds* P;
+    const uint8_t* byte_tok;
+    uint32_t* tmp;
+    unsigned long long* tmp64;
+    Seg* segtmp;
+    long long* lvars;
+    uint8_t* xb;
+};
+
+// One window: symbols [k * kWin, (k + 1) * kWin) of the L symbol bytes `sp` of a pre-token whose image is `img` and
+// whose window counters are live[0 ..].  Whole workgroup.  Returns (uniformly) the number of tokens it wrote.
+__device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace& W, const SlowShared& H, const uint8_t* sp, uint32_t L,
+                                                uint32_t k, int32_t* img, uint32_t* live, const uint8_t* buf_lo, const uint8_t* buf_hi) {
+    SlowLds& S = *H.S;
+    PieceLds& P = *H.P;
+    const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)lane_id(), wave = (uint32_t)wave_id();
+    uint32_t* const sy_a = S.arena;
+    uint32_t* const pq_a = S.arena + kMergeArena;
+    const uint32_t lo = k * (uint32_t)kWin;
+    const uint32_t hi = L - lo < (uint32_t)kWin ? L : lo + (uint32_t)kWin;
+    const uint32_t back = lo < (uint32_t)kWinBack ? lo : (uint32_t)kWinBack;
+    const uint32_t o0 = lo - back;                       // symbol position of wb[0]
+    const uint32_t n_ex = hi - o0;                       // examined positions: wb[0 .. n_ex)
+    const uint32_t avail = L - o0 < n_ex + (uint32_t)kWinAhead ? L - o0 : n_ex + (uint32_t)kWinAhead;
+    __syncthreads();
+    // the bytes, as aligned 16-byte loads wherever a whole piece lies inside the buffer [buf_lo, buf_hi)
+    const uint32_t shift = (uint32_t)(((uintptr_t)(sp + o0)) & 15u);
+    {
+        const uint8_t* const al = sp + o0 - shift;
+        const uint32_t n_chunks = (shift + avail + 15u) / 16u;
+        for (uint32_t c = (uint32_t)tid; c < n_chunks; c += kSlowThreads) {
+            const uint8_t* src = al + 16u * c;
+            if (src >= buf_lo && src + 16 <= buf_hi) {
+                *reinterpret_cast<uint4*>(&P.wraw[16u * c]) = *reinterpret_cast<const uint4*>(src);
+            } else {
+                for (uint32_t j = 0; j < 16u; j++) P.wraw[16u * c + j] = (src + j >= buf_lo && src + j < buf_hi) ? src[j] : (uint8_t)0;
+            }
+        }
+    }
+    const uint8_t* const wb = P.wraw + shift;   // wb[j] = symbol o0 + j, j < avail (what lies behind is unspecified)
+    __syncthreads();
+#if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 0
+    return 0;
+#endif
+    // Match length at each of this thread's consecutive positions.  A walk is a chain of dependent table probes (is the
+    // string one byte longer still a prefix of an entry?), and a wave waits for its longest chain; so a step probes
+    // FOUR lengths at once -- the bytes are in LDS, the hashes of the longer strings cost nothing to form ahead, and
+    // what counts is the first length that fails -- for kWalkPos positions together: a step is one memory round trip.
+    const uint32_t p0 = (uint32_t)tid * (uint32_t)kWinPer;
+    uint32_t mlen[kWinPer];
+    constexpr int kWalkPos = 4;
+    static_assert(kWinPer % kWalkPos == 0, "positions are walked in groups");
+#pragma unroll
+    for (int g = 0; g < kWinPer; g += kWalkPos) {
+        uint32_t hh[kWalkPos], ok[kWalkPos];
+        uint32_t alive = 0;
+        {   // lengths 2 (exact table) and 3, 4, 5
+            uint32_t w2[kWalkPos], w3[kWalkPos], w4[kWalkPos], w5[kWalkPos];
+#pragma unroll
+            for (int j = 0; j < kWalkPos; j++) {
+                const uint32_t p = p0 + (uint32_t)(g + j);
+                const uint32_t a = wb[p], b = wb[p + 1];
+                const uint32_t h2 = cut_hash2(a, b), h3 = cut_hash_add(h2, wb[p + 2]), h4 = cut_hash_add(h3, wb[p + 3]),
+                               h5 = cut_hash_add(h4, wb[p + 4]);
+                hh[j] = h5;
+                const uint32_t b3 = cut_hash_bit(h3, T.bloom_log2), b4 = cut_hash_bit(h4, T.bloom_log2), b5 = cut_hash_bit(h5, T.bloom_log2);
+                w2[j] = (T.prefix2[(a << 3) | (b >> 5)] >> (b & 31u)) & 1u;
+                w3[j] = (T.prefix_bloom[b3 >> 5] >> (b3 & 31u)) & 1u;
+                w4[j] = (T.prefix_bloom[b4 >> 5] >> (b4 & 31u)) & 1u;
+                w5[j] = (T.prefix_bloom[b5 >> 5] >> (b5 & 31u)) & 1u;
+            }
+#pragma unroll
+            for (int j = 0; j < kWalkPos; j++) {
+                const uint32_t p = p0 + (uint32_t)(g + j);
+                const uint32_t room = p < n_ex ? avail - p : 0u;   // bytes from p to the end of what may be matched (>= 1)
+                uint32_t l = 1;
+                if (room >= 2 && w2[j]) { l = 2; if (room >= 3 && w3[j]) { l = 3; if (room >= 4 && w4[j]) { l = 4; if (room >= 5 && w5[j]) l = 5; } } }
+                mlen[g + j] = l;
+                ok[j] = l == 5 && room > 5;
+                if (ok[j]) alive |= 1u << j;
+            }
+        }
+        while (alive) {   // four more lengths per step
+            uint32_t w[kWalkPos][4], hn[kWalkPos];
+#pragma unroll
+            for (int j = 0; j < kWalkPos; j++) {
+                const uint32_t p = p0 + (uint32_t)(g + j);
+                const uint32_t at = ok[j] ? p + mlen[g + j] : 0u;   // (idle lanes probe wb[0 ..]: in bounds, ignored)
+                uint32_t h = hh[j];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    h = cut_hash_add(h, wb[at + (uint32_t)t]);
+                    const uint32_t bit = cut_hash_bit(h, T.bloom_log2);
+                    w[j][t] = (T.prefix_bloom[bit >> 5] >> (bit & 31u)) & 1u;
+                }
+                hn[j] = h;
+            }
+#pragma unroll
+            for (int j = 0; j < kWalkPos; j++) {
+                if (!ok[j]) continue;
+                const uint32_t p = p0 + (uint32_t)(g + j);
+                uint32_t l = mlen[g + j];
+                uint32_t lim = avail - p;
+                if (lim > (uint32_t)kMaxTokenBytes) lim = (uint32_t)kMaxTokenBytes;
+                int t = 0;
+                while (t < 4 && l < lim && w[j][t]) { l++; t++; }
+                mlen[g + j] = l;
+                hh[j] = hn[j];
+                if (!(t == 4 && l < lim)) { ok[j] = 0; alive &= ~(1u << j); }
+            }
+        }
+    }
+    // furthest reach before each position (window-local): own earlier positions, earlier threads
+    uint32_t own = 0, pre[kWinPer];
+#pragma unroll
+    for (int j = 0; j < kWinPer; j++) {
+        pre[j] = own;
+        const uint32_t p = p0 + (uint32_t)j;
+        if (p < n_ex) { const uint32_t r = p + mlen[j]; own = r > own ? r : own; }
+    }
+    uint32_t inc = own;   // inclusive max-scan over the threads
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc = o > inc ? o : inc;
+    }
+    if (lane == 63) P.tmp[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+        const uint32_t x = P.tmp[w2];
+        if (w2 < wave) before = x > before ? x : before;
+        all = x > all ? x : all;
+    }
+    {
+        const uint32_t ex = __shfl_up(inc, 1, 64);
+        if (lane > 0) before = ex > before ? ex : before;
+    }
+    uint32_t cuts = 0;   // cuts at OWN positions (the look-behind only supplies reaches)
+#pragma unroll
+    for (int j = 0; j < kWinPer; j++) {
+        const uint32_t p = p0 + (uint32_t)j;
+        const uint32_t pm = pre[j] > before ? pre[j] : before;
+        if (p >= back && p < n_ex && pm <= p) cuts |= 1u << j;
+    }
+    uint32_t k_total;
+    const uint32_t kbase = block_escan<kSlowThreads / 64>((uint32_t)__popc(cuts), P.tmp + 8, &k_total);
+    {
+        uint32_t kk = kbase, c = cuts;
+        while (c) { const int j = __builtin_ctz(c); c &= c - 1; P.pl[kk++] = (uint16_t)(p0 + (uint32_t)j); }
+    }
+    __syncthreads();
+    if (k_total == 0) return 0;   // (uniform) the whole window lies inside a piece that started earlier
+#if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 1
+    return 0;
+#endif
+    // where the last piece ends: at the end of the pre-token, at the window's end if that is a cut, else at the first cut
+    // behind it -- found by walking on, one position per thread and step
+    uint32_t last_end = n_ex;      // window-local, may lie far beyond the window
+    if (hi < L && all > n_ex) {
+        uint32_t carry = all;      // furthest reach of all positions before `pos` (window-local)
+        uint32_t pos = n_ex;
+        for (;;) {
+            const uint32_t p = pos + (uint32_t)tid;
+            const uint32_t pa = o0 + p;   // symbol position
+            uint32_t r = 0;
+            if (pa < L) r = p + cut_match_len(T.prefix2, T.prefix_bloom, T.bloom_log2, [&](uint32_t i) { return (uint32_t)sp[pa + i]; }, L - pa);
+            uint32_t inc2 = r;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc2, d, 64);
+                if (lane >= (uint32_t)d) inc2 = o > inc2 ? o : inc2;
+            }
+            __syncthreads();
+            if (lane == 63) P.tmp[wave] = inc2;
+            __syncthreads();
+            uint32_t bef = carry, al = carry;
+            for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+                const uint32_t x = P.tmp[w2];
+                if (w2 < wave) bef = x > bef ? x : bef;
+                al = x > al ? x : al;
+            }
+            const uint32_t ex = __shfl_up(inc2, 1, 64);
+            if (lane > 0) bef = ex > bef ? ex : bef;
+            const bool cut = pa < L && bef <= p;
+            const unsigned long long cm = __ballot(cut);
+            if (lane == 0) P.tmp[8 + wave] = cm ? pos + wave * 64u + (uint32_t)__builtin_ctzll(cm) : 0xFFFFFFFFu;
+            __syncthreads();
+            uint32_t fc = 0xFFFFFFFFu;
+            for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) fc = P.tmp[8 + w2] < fc ? P.tmp[8 + w2] : fc;
+            if (fc != 0xFFFFFFFFu) { last_end = fc; break; }
+            pos += kSlowThreads;
+            if (o0 + pos >= L) { last_end = L - o0; break; }
+            carry = al;
+        }
+        __syncthreads();
+    }
+#if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 2
+    return 0;
+#endif
+    const uint32_t range_hi = lo + (uint32_t)kWin;   // slots from here on belong to the next window's counter
+    const bool whole_single = k_total == 1 && lo == 0 && last_end == L;   // the pre-token is one piece (o0 == 0)
+    uint32_t own_cnt = 0, nxt_cnt = 0, long_cnt = 0;
+    // single symbols need no merge: their token goes straight to the image; the others are listed
+    uint32_t n_multi = 0;
+#pragma unroll 1
+    for (uint32_t i0 = 0; i0 < k_total; i0 += kSlowThreads) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        const bool have = i < k_total;
+        const uint32_t s = have ? P.pl[i] : 0u;
+        const uint32_t e = have ? (i + 1 < k_total ? (uint32_t)P.pl[i + 1] : last_end) : 0u;
+        const bool multi = have && (e - s >= 2 || whole_single);
+        if (have && !multi) { img[(uint64_t)o0 + s] = H.byte_tok[wb[s]]; own_cnt++; }
+        uint32_t tot;
+        const uint32_t ex = block_escan<kSlowThreads / 64>(multi ? 1u : 0u, P.tmp, &tot);
+        if (multi) P.ml[n_multi + ex] = (uint16_t)i;
+        n_multi += tot;
+    }
+    __syncthreads();
+#if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 3
+    return 0;
+#endif
+#pragma unroll 1
+    for (uint32_t i0 = 0; i0 < n_multi; i0 += kSlowThreads) {
+        const bool have = i0 + (uint32_t)tid < n_multi;
+        const uint32_t i = have ? P.ml[i0 + (uint32_t)tid] : 0u;
+        const uint32_t s = have ? P.pl[i] : 0u;
+        const uint32_t e = have ? (i + 1 < k_total ? (uint32_t)P.pl[i + 1] : last_end) : 0u;
+        const uint32_t plen = e - s;
+        const uint64_t q = (uint64_t)o0 + s;
+        const bool is_long = have && (plen > (uint32_t)kLaneMax || whole_single);
+        uint32_t cnt = 0;
+        __syncthreads();   // the union is free (a rounds_piece of the previous chunk is over)
+        // -- 2 .. 16 symbols: a 16-element slot per lane
+        {
+            const bool act = have && !is_long && plen <= 16;
+            uint32_t* sy = sy_a + tid * 17;
+            uint32_t* pq = pq_a + tid * 17;
+            if (act) {
+                uint32_t bb[16], pp[15];
+#pragma unroll
+                for (int j = 0; j < 16; j++) bb[j] = wb[s + (uint32_t)j];
+#pragma unroll
+                for (int j = 0; j < 15; j++) pp[j] = (uint32_t)(j + 1) < plen ? T.bytepair[(bb[j] << 8) | bb[j + 1]] : kNoPrio;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t nxt = (uint32_t)(j + 1) < plen ? (uint32_t)(j + 1) : kNone, prv = j ? (uint32_t)(j - 1) : kNone;
+                    sy[j] = (uint32_t)H.byte_tok[bb[j]] | (nxt << 17) | (prv << 24);
+                    pq[j] = (j < 15 && pp[j < 15 ? j : 0] != kNoPrio && (uint32_t)j < plen) ? (pp[j < 15 ? j : 0] << 7) | (uint32_t)j : 0xFFFFFFFFu;
+                }
+                lane_merge<16>(T, sy, pq);
+                cnt = slot_to_image(sy, img, q, plen);
+            }
+        }
+        // -- 17 .. kLaneMax symbols: groups of 64 lanes, 64-element slots of the same arena
+        const bool is_mid = have && !is_long && plen > 16;
+        const int n_mid = __syncthreads_count(is_mid);
+        if (n_mid) {
+            uint32_t tot;
+            const uint32_t ord = block_escan<kSlowThreads / 64>(is_mid ? 1u : 0u, P.tmp, &tot);
+#pragma unroll 1
+            for (uint32_t g = 0; g * 64u < (uint32_t)n_mid; g++) {
+                const bool act = is_mid && ord / 64u == g;
+                uint32_t* sy = sy_a + (ord % 64u) * 65u;
+                uint32_t* pq = pq_a + (ord % 64u) * 65u;
+                if (act) {
+                    uint32_t prev = wb[s];
+                    for (uint32_t j = 0; j < 64; j++) {
+                        if (j < plen) {
+                            const uint32_t cur = j + 1 < plen ? (uint32_t)wb[s + j + 1] : 0u;
+                            const uint32_t pr = j + 1 < plen ? T.bytepair[(prev << 8) | cur] : kNoPrio;
+                            sy[j] = (uint32_t)H.byte_tok[prev] | ((j + 1 < plen ? j + 1 : kNone) << 17) | ((j ? j - 1 : kNone) << 24);
+                            pq[j] = pr != kNoPrio ? (pr << 7) | j : 0xFFFFFFFFu;
+                            prev = cur;
+                        } else {
+                            pq[j] = 0xFFFFFFFFu;
+                        }
+                    }
+                    lane_merge<64>(T, sy, pq);
+                    cnt = slot_to_image(sy, img, q, plen);
+                }
+                __syncthreads();
+            }
+        }
+        if (cnt) {   // which window's slots hold them
+            const uint32_t a = (uint64_t)range_hi > q ? ((uint64_t)range_hi - q < cnt ? (uint32_t)((uint64_t)range_hi - q) : cnt) : 0u;
+            own_cnt += a; nxt_cnt += cnt - a;
+        }
+        // -- longer pieces of this chunk, one after the other by the whole workgroup
+        const int n_long = __syncthreads_count(is_long);
+        if (n_long) {
+            const unsigned long long lm0 = __ballot(is_long);
+            if (lane == 0) { P.tmp[wave * 2] = (uint32_t)lm0; P.tmp[wave * 2 + 1] = (uint32_t)(lm0 >> 32); }
+            __syncthreads();
+#pragma unroll 1
+            for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+                unsigned long long lm = (unsigned long long)P.tmp[w2 * 2] | ((unsigned long long)P.tmp[w2 * 2 + 1] << 32);
+                while (lm) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(lm);
+                    lm &= lm - 1ull;
+                    const uint32_t pi = P.ml[i0 + w2 * 64u + b];
+                    const uint32_t ps = P.pl[pi], pe = pi + 1 < k_total ? (uint32_t)P.pl[pi + 1] : last_end;
+                    const uint64_t pq0 = (uint64_t)o0 + ps;
+                    const uint32_t n_out = rounds_piece(T, W, S, sp, pq0, pe - ps, whole_single, img, H.tmp, H.tmp64, H.segtmp, H.lvars, H.xb);
+                    long_cnt += n_out;
+                    if (tid == 0) {   // its tokens may lie in the slots of several windows
+                        uint64_t a = pq0;
+                        const uint64_t end = pq0 + n_out;
+                        while (a < end) {
+                            const uint64_t r = a / (uint64_t)kWin, rh = (r + 1) * (uint64_t)kWin;
+                            const uint64_t z = end < rh ? end : rh;
+                            atomicAdd(&live[r], (uint32_t)(z - a));
+                            a = z;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // the tokens of this window's short pieces: own slots / the next window's slots
+    __syncthreads();
+    {
+        uint32_t a = own_cnt, b = nxt_cnt;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+        if (lane == 0) { P.tmp[wave] = a; P.tmp[4 + wave] = b; }
+    }
+    __syncthreads();
+    uint32_t a = 0, b = 0;
+    for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) { a += P.tmp[w2]; b += P.tmp[4 + w2]; }
+    if (tid == 0) {
+        if (a) atomicAdd(&live[k], a);
+        if (b) atomicAdd(&live[k + 1], b);
+    }
+    return a + b + long_cnt;
+}
+
+#ifndef L3_SLOW_OCC
+#define L3_SLOW_OCC 1
+#endif
+__global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables T, Workspace W, EncodeArgs A) {
     __shared__ __align__(16) SlowLds S;
     __shared__ __align__(16) PieceLds P;
     __shared__ uint8_t byte_tok[256];
@@ -1773,123 +2198,72 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
     __shared__ int ivars[4];
     __shared__ uint8_t xb[kMaxTokenBytes];
 
-    if (W.status->flags & kBadOffsets) return;
+    if (W.status->flags & (kFatalFlags | kOvfWin | kOvfPool)) return;   // (the window list may be incomplete then)
     const int tid = threadIdx.x;
-    const uint32_t n_big = W.status->slow_q.count;  // final: mid_kernel has run
-    if (blockIdx.x >= n_big) return;
+    const uint32_t n_items = W.status->slow_q.count;  // final: the preparation pass has run
+    if (blockIdx.x >= n_items) return;
     for (int i = tid; i < 256; i += kSlowThreads) byte_tok[i] = T.byte_tok[i];
-    uint32_t* const sy_a = S.arena;
-    uint32_t* const pq_a = S.arena + kMergeArena;
-    bool first = true;  // the first entry needs no counter: workgroup g starts at g
-    // Entries of known, moderate length were mid_kernel's; the rest, a workgroup per entry:
-    // The entries differ in length by three orders of magnitude, so they are handed out one at a time from a counter
-    // (a fixed split left the workgroup with the longest entries running long after the others).  Every workgroup
-    // leaves at the first index past the end.
+    const SlowShared H{&S, &P, byte_tok, tmp, tmp64, segtmp, lvars, xb};
+    bool first = true;  // the first item needs no counter: workgroup g starts at g
+    // Window items differ in cost by orders of magnitude (a window inside a long piece is nothing, the window that owns
+    // that piece merges all of it), so they are handed out one at a time from a counter.
 #pragma unroll 1
     for (;;) {
         __syncthreads();
         if (tid == 0) ivars[1] = first ? (int)blockIdx.x : (int)(gridDim.x + atomicAdd(&W.status->slow_q.next, 1u));
         first = false;
         __syncthreads();
-        if ((uint32_t)ivars[1] >= n_big) break;
-        const uint64_t ei = W.slow[(uint32_t)ivars[1]].pad;
+        if ((uint32_t)ivars[1] >= n_items) break;
+        const WinItem it = W.win[(uint32_t)ivars[1]];
+        const uint32_t ei = it.entry;
         const uint64_t start = W.slow[ei].start;
-        uint64_t len = W.slow[ei].len;
-        // ---- 1. where does it end? (state_machine.go:53-79 continues until the next matcher start)
-        if (len == 0) {
-            RegionLds& R = S.R;
-            if (tid == 0) {  // end of its document: first offset > start
-                uint64_t lo = 1, hi = A.n_docs;
-                while (lo < hi) {
-                    uint64_t mid = (lo + hi) / 2;
-                    if (A.doc_off[mid] > start) hi = mid; else lo = mid + 1;
-                }
-                lvars[0] = (long long)A.doc_off[lo];
+        const uint32_t len = W.slow[ei].len;
+        const uint64_t win0 = W.slow[ei].win0;
+        const bool sequential = (win0 & kEntrySequential) != 0;
+        uint32_t* const live = W.win_live + (win0 & ~kEntrySequential);
+        const uint64_t slots = sequential ? 3ull * len : (uint64_t)len;
+        int32_t* const img = W.pool + W.slow[ei].pool_off + slots;   // the image lies behind the room for the final tokens
+        uint32_t total = 0;
+        if (!sequential) {
+            total = window_work(T, W, H, A.text + start, len, it.k, img, live, A.text, A.text + A.n_bytes);
+            if (tid == 0 && it.k == 0) W.slow[ei].pad = len;   // its symbols
+        } else {
+            if (it.k != 0) continue;   // one item works through all the windows of a pre-token with invalid UTF-8
+            // symbols: one per byte, EF BF BD for a byte that is not valid UTF-8 (state_machine.go:36), written out
+            // to the scratch; every wave takes one contiguous range of the bytes, 64 at a time (order by ballots)
+            GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
+            const uint32_t lane = (uint32_t)lane_id(), wave = (uint32_t)wave_id();
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const uint32_t bw = ((len + kSlowThreads - 1) / kSlowThreads) * 64u;
+            const uint32_t b0 = wave * bw < len ? wave * bw : len;
+            const uint32_t b1 = b0 + bw < len ? b0 + bw : len;
+            uint32_t nsym = 0;
+            for (uint32_t base = b0; base < b1; base += 64) {
+                const uint32_t q = base + lane;
+                const bool in = q < b1;
+                const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
+                nsym += (uint32_t)__popcll(__ballot(in)) + 2u * (uint32_t)__popcll(__ballot(inv));
             }
+            if (lane == 0) tmp[wave] = nsym;
             __syncthreads();
-            const uint64_t doc_end = (uint64_t)lvars[0];
-            uint64_t w0 = W.slow[ei].scan_from;
-            uint64_t end = doc_end;
-            for (;;) {
-                const uint64_t g_lo = w0 - kSBack;
-                const uint64_t g_hi = g_lo + kSRegion < doc_end ? g_lo + kSRegion : doc_end;
-                const int n = (int)(g_hi - g_lo);
-                const bool hard = g_hi == doc_end;
-                const int eval_hi = hard ? n : n - kEvalSlack;
-                for (int i = tid; i < kBitWords; i += kSlowThreads) { R.dsb[i] = 0; }
-                if (tid == 0) ivars[0] = n;
-                region_load(R, A.text, g_lo, n);
-                __syncthreads();
-                LdsSrc src{&R, n, hard};
-                region_classify(R, src, T, !(A.flags & kNoSpecial));
-                const int c0 = tid * kPer;
-                int found = n;
-                for (int j = 0; j < kPer; j++) {
-                    int q = c0 + j;
-                    if (q < kSBack || q >= eval_hi) continue;
-                    uint32_t w = R.a[q];
-                    if (!(w & I_RUNE) || (w & I_SPBODY)) continue;
-                    // a pre-token this long holds no digit, so no digit-run offset is needed
-                    if (starts_pretoken(src, q, 0)) { found = q; break; }
-                }
-                if (found < n) atomicMin(&ivars[0], found);
-                __syncthreads();
-                const int f = ivars[0];
-                __syncthreads();
-                if (f < n) { end = g_lo + (uint64_t)f; break; }
-                if (hard) { end = doc_end; break; }
-                w0 = g_lo + (uint64_t)eval_hi;
+            uint32_t L = 0, so = 0;
+            for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+                const uint32_t x = tmp[w2];
+                if (w2 < wave) so += x;
+                L += x;
             }
-            len = end - start;
-        }
-        // ---- 2. symbols: one per byte, EF BF BD for a byte that is not valid UTF-8 (state_machine.go:36)
-        GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
-        // every wave takes one contiguous range of the bytes, 64 at a time (coalesced reads, order by ballots)
-        const uint32_t lane = (uint32_t)lane_id(), wave = (uint32_t)wave_id();
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const uint64_t bw = ((len + kSlowThreads - 1) / kSlowThreads) * 64u;
-        const uint64_t b0 = wave * bw < len ? wave * bw : len;
-        const uint64_t b1 = b0 + bw < len ? b0 + bw : len;
-        uint32_t nsym = 0;
-        for (uint64_t base = b0; base < b1; base += 64) {
-            const uint64_t q = base + lane;
-            const bool in = q < b1;
-            const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
-            nsym += (uint32_t)__popcll(__ballot(in)) + 2u * (uint32_t)__popcll(__ballot(inv));
-        }
-        if (lane == 0) tmp[wave] = nsym;
-        __syncthreads();
-        uint32_t L = 0, so = 0;
-        for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
-            const uint32_t x = tmp[w2];
-            if (w2 < wave) so += x;
-            L += x;
-        }
-        __syncthreads();
-        // room: L image slots in the slow pool; the expanded bytes of a pre-token with invalid UTF-8 in the scratch
-        const bool has_inv = (uint64_t)L != len;
-        if (tid == 0) {
-            const unsigned long long off = atomicAdd(&W.status->pool_used, (unsigned long long)L);
-            const bool fits = off + L <= W.pool_cap;
-            if (!fits) atomicOr(&W.status->flags, kOvfPool);
-            lvars[4] = fits ? (long long)off : -1ll;
-            lvars[5] = 0;
-            if (has_inv) {
+            if (tid == 0) {
                 const unsigned long long need = ((unsigned long long)L + 31ull) & ~15ull;
                 const unsigned long long so2 = atomicAdd(&W.status->scratch_used, need);
                 lvars[5] = (so2 + need <= W.scratch_cap) ? (long long)so2 : -1ll;
                 if (so2 + need > W.scratch_cap) atomicOr(&W.status->flags, kOvfScratch);
             }
-        }
-        __syncthreads();
-        if (lvars[4] < 0 || lvars[5] < 0) continue;   // (uniform) the host grows the lists and runs the batch again
-        int32_t* const img = W.pool + (unsigned long long)kMissShards * W.mpool_shard_cap + (unsigned long long)lvars[4];
-        const uint8_t* sp = A.text + start;
-        if (has_inv) {
+            __syncthreads();
+            if (lvars[5] < 0) continue;   // (uniform) the host grows the scratch and runs the batch again
             uint8_t* xs = W.scratch + lvars[5];
             uint32_t o = so;
-            for (uint64_t base = b0; base < b1; base += 64) {
-                const uint64_t q = base + lane;
+            for (uint32_t base = b0; base < b1; base += 64) {
+                const uint32_t q = base + lane;
                 const bool in = q < b1;
                 const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
                 const unsigned long long mi = __ballot(in), mv = __ballot(inv);
@@ -1901,242 +2275,89 @@ __global__ __launch_bounds__(kSlowThreads) void slow_kernel(Tables T, Workspace 
                 }
                 o += (uint32_t)__popcll(mi) + 2u * (uint32_t)__popcll(mv);
             }
-            sp = xs;
             __syncthreads();
+            const uint32_t nw = (L + (uint32_t)kWin - 1) / (uint32_t)kWin;
+#pragma unroll 1
+            for (uint32_t kk = 0; kk < nw; kk++) total += window_work(T, W, H, xs, L, kk, img, live, xs, xs + (((uint64_t)L + 31ull) & ~15ull));
+            if (tid == 0) W.slow[ei].pad = L;
         }
-        // ---- 3. windows: cuts, pieces, merges
-        uint32_t open_start = 0, w0 = 0, carry = 0;   // symbol positions; carry = furthest reach of the positions before w0
-#pragma unroll 1
-        while (w0 < L) {
-            const uint32_t n = L - w0 < (uint32_t)kWin ? L - w0 : (uint32_t)kWin;
-            const uint32_t avail = L - w0 < (uint32_t)(kWin + kWinAhead) ? L - w0 : (uint32_t)(kWin + kWinAhead);
-            __syncthreads();
-            for (uint32_t i = (uint32_t)tid * 16u; i < avail + 16u && i < (uint32_t)sizeof(P.wb); i += kSlowThreads * 16u) {
-                const uint8_t* src = sp + w0 + i;
-                if (i + 16u <= avail && (((uintptr_t)src) & 15u) == 0) {
-                    *reinterpret_cast<uint4*>(&P.wb[i]) = *reinterpret_cast<const uint4*>(src);
-                } else {
-                    for (uint32_t k = 0; k < 16u; k++) P.wb[i + k] = i + k < avail ? src[k] : (uint8_t)0;
-                }
-            }
-            __syncthreads();
-            // match length at each of this thread's 16 consecutive positions, all walks in step (independent loads)
-            const uint32_t p0 = (uint32_t)tid * (uint32_t)kWinPer;
-            uint32_t mlen[kWinPer], hh[kWinPer];
-            uint32_t alive = 0;
-#pragma unroll
-            for (int j = 0; j < kWinPer; j++) {
-                const uint32_t p = p0 + (uint32_t)j;
-                mlen[j] = 1; hh[j] = 0;
-                if (p < n && p + 1 < avail) {
-                    const uint32_t a = P.wb[p], b = P.wb[p + 1];
-                    if ((T.prefix2[(a << 3) | (b >> 5)] >> (b & 31u)) & 1u) { mlen[j] = 2; hh[j] = cut_hash2(a, b); alive |= 1u << j; }
-                }
-            }
-            while (alive) {
-                uint32_t word[kWinPer], h2[kWinPer];
-#pragma unroll
-                for (int j = 0; j < kWinPer; j++) {
-                    word[j] = 0; h2[j] = 0;
-                    if ((alive >> j) & 1u) {
-                        const uint32_t p = p0 + (uint32_t)j;
-                        if (p + mlen[j] < avail && mlen[j] < (uint32_t)kMaxTokenBytes) {
-                            h2[j] = cut_hash_add(hh[j], P.wb[p + mlen[j]]);
-                            const uint32_t bit = cut_hash_bit(h2[j], T.bloom_log2);
-                            word[j] = (T.prefix_bloom[bit >> 5] >> (bit & 31u)) & 1u;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kWinPer; j++) {
-                    if ((alive >> j) & 1u) {
-                        if (word[j]) { mlen[j]++; hh[j] = h2[j]; } else alive &= ~(1u << j);
-                    }
-                }
-            }
-            // furthest reach before each position: own earlier positions, earlier threads, earlier windows
-            uint32_t own = 0, pre[kWinPer];
-#pragma unroll
-            for (int j = 0; j < kWinPer; j++) {
-                pre[j] = own;
-                const uint32_t p = p0 + (uint32_t)j;
-                if (p < n) { const uint32_t r = p + mlen[j]; own = r > own ? r : own; }
-            }
-            uint32_t inc = own;   // inclusive max-scan over the threads
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(inc, d, 64);
-                if (lane >= (uint32_t)d) inc = o > inc ? o : inc;
-            }
-            if (lane == 63) P.tmp[wave] = inc;
-            __syncthreads();
-            uint32_t before = carry > w0 ? carry - w0 : 0u, all = before;
-            for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
-                const uint32_t x = P.tmp[w2];
-                if (w2 < wave) before = x > before ? x : before;
-                all = x > all ? x : all;
-            }
-            {
-                const uint32_t ex = __shfl_up(inc, 1, 64);
-                if (lane > 0) before = ex > before ? ex : before;
-            }
-            uint32_t cuts = 0;
-#pragma unroll
-            for (int j = 0; j < kWinPer; j++) {
-                const uint32_t p = p0 + (uint32_t)j;
-                const uint32_t pm = pre[j] > before ? pre[j] : before;
-                if (p < n && pm <= p) cuts |= 1u << j;
-            }
-            P.cutw[tid] = (uint16_t)cuts;
-            uint32_t k_total;
-            const uint32_t kbase = block_escan<kSlowThreads / 64>((uint32_t)__popc(cuts), P.tmp + 8, &k_total);
-            {
-                uint32_t k = kbase, c = cuts;
-                while (c) { const int j = __builtin_ctz(c); c &= c - 1; P.pl[k++] = (uint16_t)(p0 + (uint32_t)j); }
-            }
-            const bool at_end = w0 + n == L;
-            if (tid == 0 && at_end) P.pl[k_total] = (uint16_t)n;
-            __syncthreads();
-            // a piece that began in an earlier window (longer than a window): it ends at this window's first cut
-            if (open_start < w0) {
-                if (k_total > 0) {
-                    const uint32_t c0 = P.pl[0];
-                    rounds_piece(T, W, S, sp, open_start, w0 + c0 - open_start, false, img, tmp, tmp64, segtmp, lvars, xb);
-                    open_start = w0 + c0;
-                } else if (at_end) {
-                    rounds_piece(T, W, S, sp, open_start, L - open_start, open_start == 0, img, tmp, tmp64, segtmp, lvars, xb);
-                    break;
-                } else {
-                    carry = w0 + all;
-                    w0 += n;
-                    continue;
-                }
-            }
-            // complete pieces of this window: [pl[i], pl[i + 1]), i < n_complete
-            const uint32_t n_complete = at_end ? k_total : k_total - 1u;   // (k_total >= 1 here)
-            const bool whole_single = at_end && k_total == 1 && w0 == 0 && open_start == 0;   // the pre-token is one piece
-#pragma unroll 1
-            for (uint32_t i0 = 0; i0 < n_complete; i0 += kSlowThreads) {
-                const uint32_t i = i0 + (uint32_t)tid;
-                const bool have = i < n_complete;
-                const uint32_t s = have ? P.pl[i] : 0u;
-                const uint32_t plen = have ? (uint32_t)P.pl[i + 1] - s : 0u;
-                const uint64_t q = (uint64_t)w0 + s;
-                const bool is_long = have && (plen > (uint32_t)kLaneMax || whole_single);
-                if (have && plen == 1 && !is_long) img[q] = byte_tok[P.wb[s]];
-                __syncthreads();   // the union is free (a rounds_piece of the previous chunk is over)
-                // -- 2 .. 16 symbols: a 16-element slot per lane
-                {
-                    const bool act = have && !is_long && plen >= 2 && plen <= 16;
-                    uint32_t* sy = sy_a + tid * 17;
-                    uint32_t* pq = pq_a + tid * 17;
-                    if (act) {
-                        uint32_t bb[16], pp[15];
-#pragma unroll
-                        for (int j = 0; j < 16; j++) bb[j] = P.wb[s + (uint32_t)j];
-#pragma unroll
-                        for (int j = 0; j < 15; j++) pp[j] = (uint32_t)(j + 1) < plen ? T.bytepair[(bb[j] << 8) | bb[j + 1]] : kNoPrio;
-#pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const uint32_t nxt = (uint32_t)(j + 1) < plen ? (uint32_t)(j + 1) : kNone, prv = j ? (uint32_t)(j - 1) : kNone;
-                            sy[j] = (uint32_t)byte_tok[bb[j]] | (nxt << 17) | (prv << 24);
-                            pq[j] = (j < 15 && pp[j < 15 ? j : 0] != kNoPrio && (uint32_t)j < plen) ? (pp[j < 15 ? j : 0] << 7) | (uint32_t)j : 0xFFFFFFFFu;
-                        }
-                        lane_merge<16>(T, sy, pq);
-                        slot_to_image(sy, img, q, plen);
-                    }
-                }
-                // -- 17 .. kLaneMax symbols: groups of 64 lanes, 64-element slots of the same arena
-                const bool is_mid = have && !is_long && plen > 16;
-                const int n_mid = __syncthreads_count(is_mid);
-                if (n_mid) {
-                    uint32_t tot;
-                    const uint32_t ord = block_escan<kSlowThreads / 64>(is_mid ? 1u : 0u, P.tmp, &tot);
-#pragma unroll 1
-                    for (uint32_t g = 0; g * 64u < (uint32_t)n_mid; g++) {
-                        const bool act = is_mid && ord / 64u == g;
-                        uint32_t* sy = sy_a + (ord % 64u) * 65u;
-                        uint32_t* pq = pq_a + (ord % 64u) * 65u;
-                        if (act) {
-                            uint32_t prev = P.wb[s];
-                            for (uint32_t j = 0; j < 64; j++) {
-                                if (j < plen) {
-                                    const uint32_t cur = j + 1 < plen ? (uint32_t)P.wb[s + j + 1] : 0u;
-                                    const uint32_t pr = j + 1 < plen ? T.bytepair[(prev << 8) | cur] : kNoPrio;
-                                    sy[j] = (uint32_t)byte_tok[prev] | ((j + 1 < plen ? j + 1 : kNone) << 17) | ((j ? j - 1 : kNone) << 24);
-                                    pq[j] = pr != kNoPrio ? (pr << 7) | j : 0xFFFFFFFFu;
-                                    prev = cur;
-                                } else {
-                                    pq[j] = 0xFFFFFFFFu;
-                                }
-                            }
-                            lane_merge<64>(T, sy, pq);
-                            slot_to_image(sy, img, q, plen);
-                        }
-                        __syncthreads();
-                    }
-                }
-                // -- longer pieces of this chunk, one after the other by the whole workgroup
-                if (tid < 4) P.vars[tid] = 0;
-                __syncthreads();
-                {
-                    const unsigned long long lm = __ballot(is_long);
-                    if (lane == 0) { P.tmp[wave * 2] = (uint32_t)lm; P.tmp[wave * 2 + 1] = (uint32_t)(lm >> 32); }
-                }
-                __syncthreads();
-#pragma unroll 1
-                for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
-                    unsigned long long lm = (unsigned long long)P.tmp[w2 * 2] | ((unsigned long long)P.tmp[w2 * 2 + 1] << 32);
-                    while (lm) {
-                        const uint32_t b = (uint32_t)__builtin_ctzll(lm);
-                        lm &= lm - 1ull;
-                        const uint32_t pi = i0 + w2 * 64u + b;
-                        const uint32_t ps = P.pl[pi], pe = P.pl[pi + 1];
-                        rounds_piece(T, W, S, sp, (uint64_t)w0 + ps, pe - ps, whole_single, img, tmp, tmp64, segtmp, lvars, xb);
-                    }
-                }
-            }
-            if (at_end) break;
-            const uint32_t last = P.pl[k_total - 1u];   // start of the piece still open at the end of the window
-            if (last > 0) { open_start = w0 + last; w0 = open_start; carry = w0; }   // look at it again from its start
-            else { carry = w0 + all; w0 += n; }                                      // it fills the window: go on
-        }
-        __syncthreads();
-        // ---- 4. compact the image in place (16 slots per thread and step; the write cursor never passes the reads)
-        uint32_t n_out = 0;
-#pragma unroll 1
-        for (uint32_t base = 0; base < L; base += (uint32_t)kWin) {
-            int32_t v[kWinPer];
-            const uint32_t p0 = base + (uint32_t)tid * (uint32_t)kWinPer;
-            uint32_t live = 0;
-#pragma unroll
-            for (int j = 0; j < kWinPer; j++) {
-                v[j] = p0 + (uint32_t)j < L ? img[p0 + (uint32_t)j] : -1;
-                if (v[j] >= 0) live++;
-            }
-            uint32_t tot;
-            const uint32_t ex = block_escan<kSlowThreads / 64>(live, P.tmp, &tot);   // (barriers: every read is done before a write)
-            uint32_t o = n_out + ex;
-#pragma unroll
-            for (int j = 0; j < kWinPer; j++)
-                if (v[j] >= 0) img[o++] = v[j];
-            n_out += tot;
-            __syncthreads();
-        }
-        if (tid == 0) {
-            W.slow[ei].count = n_out;
-            W.slow[ei].pool_off = (unsigned long long)kMissShards * W.mpool_shard_cap + (unsigned long long)lvars[4];
-            if (n_out > 1) atomicAdd(&W.tile_extra[W.slow[ei].tile], n_out - 1);
+        if (tid == 0 && total) {
+            atomicAdd(&W.slow[ei].count, total);
+            // tile_extra counts the tokens beyond the one the pre-token's stream item stands for
+            atomicAdd(&W.tile_extra[W.slow[ei].tile], total - ((it.k == 0) ? 1u : 0u));
         }
     }
+}
+
+// The tokens of window item `w` from the image to their final place (the windows of a pre-token in order): whole
+// workgroup of kScanBlock threads.  Runs in the launch of block_totals_kernel, i.e. after slow_kernel has finished.
+constexpr int kFinishThreads = 1024;
+constexpr int kFinishPer = (kWin + kFinishThreads - 1) / kFinishThreads;
+__device__ void finish_window(const Workspace& W, uint32_t w, unsigned long long* wsum) {
+    const int tid = threadIdx.x;
+    const WinItem it = W.win[w];
+    const uint64_t win0 = W.slow[it.entry].win0;
+    const uint32_t* live = W.win_live + (win0 & ~kEntrySequential);
+    const uint32_t mine = live[it.k];
+    if (mine == 0) return;   // (uniform)
+    const uint32_t len = W.slow[it.entry].len, L = W.slow[it.entry].pad;
+    const uint64_t slots = (win0 & kEntrySequential) ? 3ull * len : (uint64_t)len;
+    int32_t* const fin = W.pool + W.slow[it.entry].pool_off;
+    const int32_t* const img = fin + slots;
+    // tokens of the windows before this one
+    unsigned long long before = 0;
+    for (uint32_t j = (uint32_t)tid; j < it.k; j += kFinishThreads) before += live[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+    __syncthreads();
+    if (lane_id() == 0) wsum[tid >> 6] = before;
+    __syncthreads();
+    before = 0;
+    for (int i = 0; i < kFinishThreads / 64; i++) before += wsum[i];
+    __syncthreads();
+    // compaction of the window's slots: kFinishPer consecutive slots per thread
+    const uint64_t lo = (uint64_t)it.k * (uint64_t)kWin;
+    int32_t v[kFinishPer];
+    uint32_t n_live = 0;
+#pragma unroll
+    for (int j = 0; j < kFinishPer; j++) {
+        const uint32_t o = (uint32_t)tid * (uint32_t)kFinishPer + (uint32_t)j;
+        const uint64_t p = lo + o;
+        v[j] = (o < (uint32_t)kWin && p < (uint64_t)L) ? img[p] : -1;
+        if (v[j] >= 0) n_live++;
+    }
+    uint32_t inc = n_live;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane_id() >= d) inc += o;
+    }
+    if (lane_id() == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int i = 0; i < (tid >> 6); i++) pre += (uint32_t)wsum[i];
+    __syncthreads();
+    uint64_t o = before + pre + inc - n_live;
+#pragma unroll
+    for (int j = 0; j < kFinishPer; j++)
+        if (v[j] >= 0) fin[o++] = v[j];
 }
 
 // ---- per-tile output bases: block totals, scan of the block totals -----------------------------------------
 constexpr int kScanThreads = 1024;
 constexpr int kScanBlock = 1024;  // tiles per block total
-__global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, uint64_t n_tiles, uint64_t n_docs) {
+static_assert(kFinishThreads == kScanBlock, "finish_window runs in block_totals_kernel's workgroups");
+// Workgroups [0, n_blocks): the totals; the workgroups behind them move the tokens of the long pre-tokens from their
+// images to their final place (same launch: both only need what the kernels before have left).
+__global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, uint64_t n_tiles, uint64_t n_docs, uint32_t n_blocks) {
     __shared__ unsigned long long wsum[kScanBlock / 64];
-    if (W.status->flags & kBadOffsets) return;
+    if (W.status->flags & kFatalFlags) return;
+    if (blockIdx.x >= n_blocks) {
+        if (W.status->flags & kRetryFlags) return;
+        const uint32_t n_items = W.status->slow_q.count;
+        for (uint32_t w = blockIdx.x - n_blocks; w < n_items; w += gridDim.x - n_blocks) { finish_window(W, w, wsum); __syncthreads(); }
+        return;
+    }
     const uint64_t t = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;   // one tile per thread
     const uint32_t n_items = t < n_tiles ? W.tile_items[t] : 0u, n_extra = t < n_tiles ? W.tile_extra[t] : 0u;
     const uint32_t d_lo = t < n_tiles ? W.tile_doc0[t] : 0u;
@@ -2275,7 +2496,7 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
     const unsigned long long blk_base = W.tile_base[tile / kScanBlock];
     const uint32_t fl = W.status->flags;
     const unsigned long long total_tokens = W.status->total_tokens;
-    if (fl & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) return;
+    if (fl & (kFatalFlags | kRetryFlags)) return;
     if (total_tokens > A.out_cap) return;
     const uint32_t n_items = rec.n_items;
     const uint64_t n_tok = (uint64_t)n_items + rec.n_extra;
@@ -2482,7 +2703,7 @@ __global__ __launch_bounds__(kTileThreads) void emit_generic_kernel(Workspace W,
     __shared__ int32_t q_item[kEmitQueue];
     __shared__ uint32_t q_n;
     const uint32_t fl = W.status->flags;
-    if (fl & (kBadOffsets | kOvfSlow | kOvfMiss | kOvfPool | kOvfScratch)) return;
+    if (fl & (kFatalFlags | kRetryFlags)) return;
     if (W.status->total_tokens > A.out_cap) return;
     const uint64_t t0 = (uint64_t)blockIdx.x * kGenericPer;
     for (uint64_t t = t0; t < t0 + kGenericPer && t < n_tiles; t++) {
@@ -2605,7 +2826,12 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         hipLaunchKernelGGL(tile_kernel, dim3((uint32_t)n_tiles), dim3(kTileThreads), 0, stream, T, W, A);
         L3_LAUNCH_CHECK();
         L3_EV(kEvTile);
-        uint64_t sgrid = W.slow_cap < 2048 ? W.slow_cap : 2048;
+        // slow_kernel's workgroups take entries from a queue: no more of them than the GPU holds at once (an empty list
+        // then costs a short launch); the wave-per-entry pass inside merge_kernel's launch gets the same number
+#ifndef L3_SLOW_GRID
+#define L3_SLOW_GRID 512
+#endif
+        uint64_t sgrid = W.slow_cap < L3_SLOW_GRID ? W.slow_cap : L3_SLOW_GRID;
         if (sgrid == 0) sgrid = 1;
         {
             uint64_t mgrid = ((W.miss_shard_cap + kMergeThreads - 1) / kMergeThreads) * kMissShards;  // windows at most
@@ -2623,7 +2849,11 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         L3_LAUNCH_CHECK();
         L3_EV(kEvSlow);
         const uint64_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
-        hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks), dim3(kScanBlock), 0, stream, W, n_tiles, A.n_docs);
+#ifndef L3_FINISH_GRID
+#define L3_FINISH_GRID 512
+#endif
+        hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks + L3_FINISH_GRID), dim3(kScanBlock), 0, stream, W, n_tiles, A.n_docs,
+                           (uint32_t)n_blocks);
         L3_LAUNCH_CHECK();
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, W, A, n_blocks);
         L3_LAUNCH_CHECK();
