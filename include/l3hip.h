@@ -114,7 +114,8 @@ int l3_last_timings(l3_ctx* ctx, float* ms, int cap);
 int l3_timing_totals(l3_ctx* ctx, double* ms, int cap, uint64_t* calls);
 /* counters of the last encode call: [0] tiles, [1] deferred (slow) pre-tokens, [2] tokens of all
  * deferred pre-tokens, [3] scratch bytes, [4] retries after a workspace grew, [5] short deferred pre-tokens,
- * [6] window items of the long deferred pre-tokens */
+ * [6] window items of the long deferred pre-tokens, [7] symbols merged by the grid-wide path (pieces of 32,768 symbols
+ * and more that no cut divides) */
 int l3_last_counters(l3_ctx* ctx, uint64_t* out, int cap);
 
 #ifdef __cplusplus

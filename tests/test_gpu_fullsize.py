@@ -145,3 +145,32 @@ def test_host_batches_in_pieces(ctx, oracle):
     assert rc == capi.L3_E_OUTPUT_CAP and need.value == tok.size and np.array_equal(ooff, toff)
     tok2, toff2 = ctx.encode_batch(base, off, True, True, out_cap=tok.size)
     assert np.array_equal(tok2, tok) and np.array_equal(toff2, toff)
+
+
+def test_giant_pieces_grid_wide_merge(ctx, oracle):
+    """Pieces of 32,768 symbols and more that no cut divides take the grid-wide merge (l3_giant.hip): one character
+    repeated, a DNA-like string, invalid bytes (three symbols each), several such pieces in one pre-token / document /
+    batch, next to ordinary text, around the threshold, twice in a row on one context."""
+    from tokenizer_amd import capi
+    rng = np.random.default_rng(5)
+    acgt = bytes(rng.choice(np.frombuffer(b"acgt", dtype=np.uint8), 300000))
+    e_text, _ = corpora.english(64, 1024)
+    eng = e_text.tobytes()
+    docs = [
+        b"a" * 32767, b"a" * 32768, b"a" * 32769, b"b" * 100000, b" " * 70001 + b"x", acgt,
+        b"\xff" * 40000,                                        # 120,000 symbols EF BF BD ...
+        eng[:3000] + b"z" * 50000 + eng[3000:9000] + acgt[:60000] + b" " + b"!" * 45000 + eng[9000:12000],
+        "中".encode() * 20000 + b"q" * 40000 + "文".encode() * 20000,     # cuts around a giant piece inside ONE pre-token
+        b"", eng[:5000], b"ab" * 30000, b"\t" * 33000 + b"\n" * 40000,
+    ]
+    text, off = capi.pack_docs(docs)
+    for _ in range(2):
+        _same(ctx, oracle, text, off)
+        assert ctx.last_counters()["giant_symbols"] >= 32768 * 8
+    for d in (docs[1], docs[7]):
+        t, o = capi.pack_docs([d])
+        _same(ctx, oracle, t, o, threads=1)
+    # a batch without such pieces right after: nothing of the path may linger
+    t, o = capi.pack_docs([eng[:7000], b"a" * 2500])
+    _same(ctx, oracle, t, o)
+    assert ctx.last_counters()["giant_symbols"] == 0

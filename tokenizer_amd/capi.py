@@ -243,7 +243,7 @@ class Context:
         return dict(zip(["docs", "tile", "merge", "slow", "scan", "emit", "total"], a.tolist())), int(n.value)
 
     def last_counters(self):
-        a = np.zeros(7, dtype=np.uint64)
-        self.lib.l3_last_counters(self.h, a.ctypes.data, 7)
-        return dict(zip(["tiles", "slow_pretokens", "deferred_tokens", "scratch_bytes", "retries", "short_pretokens", "window_items"],
-                        a.tolist()))
+        a = np.zeros(8, dtype=np.uint64)
+        self.lib.l3_last_counters(self.h, a.ctypes.data, 8)
+        return dict(zip(["tiles", "slow_pretokens", "deferred_tokens", "scratch_bytes", "retries", "short_pretokens", "window_items",
+                         "giant_symbols"], a.tolist()))

@@ -82,6 +82,7 @@ struct l3_ctx {
     bool clear_on_own = false;        // ... on the context's own stream (same-stream order makes the wait unnecessary)
     hipEvent_t ev_clear = nullptr;
     DevBuf w_arena, w_status;         // the per-call workspace (one block, carve_workspace) and the status word
+    DevBuf w_giant;                   // flat arrays of the grid-wide merge of giant pieces (only batches that have such pieces)
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
     Caps caps{0, 0, 0, 0, 0, 0};         // list capacities inside the workspace, grow-only
     unsigned char* na_scratch = nullptr;  // this GPU's copy of the file-scope array `scratch` (hipGetSymbolAddress at l3_create)
@@ -181,8 +182,12 @@ size_t carve_workspace(uint8_t* base, uint64_t n_bytes, uint64_t n_docs, const C
     W.miss_res = reinterpret_cast<uint64_t*>(take(K.miss_shard_cap * kMissShards * sizeof(uint64_t)));
     W.pool = reinterpret_cast<int32_t*>(take((K.mpool_shard_cap * kMissShards + K.pool_cap) * sizeof(int32_t)));
     W.scratch = take(K.scratch_cap);
+    W.allow_giants = 1;
+    W.giants = reinterpret_cast<Giant*>(take(kMaxGiants * sizeof(Giant)));
+    W.gstate = reinterpret_cast<GiantState*>(take(sizeof(GiantState)));
     W.win = reinterpret_cast<WinItem*>(take(K.win_cap * sizeof(WinItem)));
     W.win_live = reinterpret_cast<uint32_t*>(take(K.win_cap * 4));
+    W.win_first = reinterpret_cast<uint32_t*>(take(K.win_cap * 4));
     W.win_cap = K.win_cap;
     W.status = status;
     W.slow_cap = K.slow_cap;
@@ -257,6 +262,38 @@ int rerun_emit(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t s
     return queue_status_clear(c, W, stream);
 }
 
+// Pieces too long for one workgroup were listed by slow_kernel (kGiantPending; the kernels behind it have skipped): the
+// grid-wide merge (l3_giant.hip) in rounds until its state says done, its tokens to the images, then the tail of the
+// pipeline.  Leaves the final status in c->h_status.  `flat`: 24 bytes per symbol (allocated here; the allocation-free
+// entry point does not come this way).
+int run_giants(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t stream, const Status& st) {
+    const uint32_t n_giants = st.giant.count < kMaxGiants ? st.giant.count : kMaxGiants;
+    HIPCHK(c, launch_giants_order(W, n_giants, stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_total, &W.gstate->n, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, hipStreamSynchronize(stream));
+    const uint64_t n_syms = *c->h_total & 0xFFFFFFFFull;   // (a sum of 2^31 and more is reported as 0xFFFFFFFF)
+    c->counters[7] = n_syms;
+    if (n_syms == 0) { c->err = "internal: empty giant list"; return L3_E_HIP; }
+    if (n_syms >= (1ull << 31)) { c->err = "pieces of 2^31 and more symbols that no cut divides: split the batch"; return L3_E_INVALID_ARG; }
+    HIPCHK(c, c->w_giant.ensure(24 * n_syms + 256));
+    HIPCHK(c, launch_giants_init(c->T, W, n_giants, n_syms, c->w_giant.p, stream));
+    bool done = false;
+    for (int it = 0; it < 1024 && !done; it++) {
+        HIPCHK(c, launch_giants_rounds(c->T, W, n_syms, c->w_giant.p, it == 0 ? 8 : 16, stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_total, &W.gstate->done, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(c, hipStreamSynchronize(stream));
+        done = (*c->h_total & 0xFFFFFFFFull) != 0;
+    }
+    if (!done) { c->err = "grid-wide merge did not finish"; return L3_E_HIP; }
+    HIPCHK(c, launch_giants_store(W, n_syms, c->w_giant.p, stream));
+    HIPCHK(c, hipMemsetAsync(&W.status->flags, 0, 8, stream));   // flags (kGiantPending) and generic_tiles
+    HIPCHK(c, launch_encode_tail(W, A, stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[kEvEmit], stream));   // the "emit" figure then holds the grid-wide merge too
+    HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, hipStreamSynchronize(stream));
+    return L3_OK;
+}
+
 // Runs the pipeline on device-resident data.  On L3_OK or L3_E_OUTPUT_CAP *n_tok is the total.
 // `W_out` (optional) receives the workspace used, so a caller can re-run the final scatter.
 int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_tok, Workspace* W_out) {
@@ -280,6 +317,26 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false));
         HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
+        c->counters[7] = 0;
+        bool redo_tail = false;
+        if ((c->h_status->flags & kSeqPending) && !(c->h_status->flags & (kFatalFlags | kRetryFlags))) {
+            // long pre-tokens with invalid UTF-8 have been expanded: their windows now, in parallel
+            HIPCHK(c, launch_slow_second_pass(c->T, W, A, stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
+            HIPCHK(c, hipStreamSynchronize(stream));
+            redo_tail = true;
+        }
+        if ((c->h_status->flags & kGiantPending) && !(c->h_status->flags & (kFatalFlags | kRetryFlags))) {
+            const Status st0 = *c->h_status;
+            if ((rc = run_giants(c, W, A, stream, st0))) return rc;
+            redo_tail = false;
+        }
+        if (redo_tail && !(c->h_status->flags & (kFatalFlags | kRetryFlags))) {
+            HIPCHK(c, launch_encode_tail(W, A, stream));
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[kEvEmit], stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
+            HIPCHK(c, hipStreamSynchronize(stream));
+        }
         if (c->h_status->generic_tiles && !(c->h_status->flags & (kFatalFlags | kRetryFlags | kOvfOut))) {
             // tiles with empty documents or token floods: the generic scatter, launched only when the fast one asks
             HIPCHK(c, launch_emit_generic(W, A, stream));
@@ -414,7 +471,7 @@ void l3_destroy(l3_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
-                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->t_prefix2, &c->t_bloom, &c->w_arena, &c->w_status, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
+                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->t_prefix2, &c->t_bloom, &c->w_arena, &c->w_status, &c->w_giant, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
                       &c->s_total};
     for (DevBuf* b : bufs) b->release();
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -500,6 +557,7 @@ int l3_encode_batch_device_noalloc(l3_ctx* c, const uint8_t* d_text, uint64_t n_
     if (need > kNoAllocScratchBytes) { c->err = "internal: static workspace too small for its own limits"; return L3_E_INVALID_ARG; }
     W.bos_id = c->H.special_id[0];
     W.eos_id = c->H.special_id[1];
+    W.allow_giants = 0;   // the grid-wide merge of very long cut-free pieces allocates: here one workgroup merges each
     EncodeArgs A{};
     A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = flags;
     A.out_tok = d_out_tok; A.out_cap = out_cap; A.out_off = d_out_off; A.kinds = nullptr;
@@ -519,7 +577,7 @@ int l3_encode_batch_device_noalloc(l3_ctx* c, const uint8_t* d_text, uint64_t n_
         c->err = "a single pre-token of 2 GiB or more is not supported";
         return L3_E_INVALID_ARG;
     }
-    if (st.flags & kRetryFlags) {
+    if (st.flags & (kRetryFlags | kGiantPending | kSeqPending)) {
         c->err = "batch needs more workspace than the static array of l3_encode_batch_device_noalloc holds (unusually many "
                  "deferred pre-tokens): use l3_encode_batch_device";
         return L3_E_SCRATCH;
@@ -588,7 +646,7 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
     }
     uint64_t total = 0, base[9];
     bool overflow = false;
-    uint64_t sum_counters[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t sum_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < S; k++) {
         const uint64_t nd = d_lo[k + 1] - d_lo[k];
         const uint64_t b0 = doc_off[d_lo[k]], nb = doc_off[d_lo[k + 1]] - b0;
@@ -614,7 +672,7 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
             if (rc == L3_OK && hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "hipStreamSynchronize failed"; rc = L3_E_HIP; }
         }
         if (rc) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamSynchronize(c->stream_out); return rc; }
-        for (int i = 0; i < 7; i++) sum_counters[i] += c->counters[i];
+        for (int i = 0; i < 8; i++) sum_counters[i] += c->counters[i];
         total += tk;
         if (total > out_cap) overflow = true;
         HIPCHK(c, hipMemcpyAsync(out_off + d_lo[k], oo.p, nd * 8, hipMemcpyDeviceToHost, c->stream_out));
@@ -626,7 +684,7 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
     for (int k = 1; k < S; k++)
         if (base[k]) for (uint64_t d = d_lo[k]; d < d_lo[k + 1]; d++) out_off[d] += base[k];
     out_off[n_docs] = total;
-    for (int i = 0; i < 7; i++) c->counters[i] = sum_counters[i];
+    for (int i = 0; i < 8; i++) c->counters[i] = sum_counters[i];
     *n_tok = total;
     if (overflow) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
     return L3_OK;
@@ -816,7 +874,7 @@ int l3_timing_totals(l3_ctx* c, double* ms, int cap, uint64_t* calls) {
 int l3_last_counters(l3_ctx* c, uint64_t* out, int cap) {
     if (!c || !out) return L3_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
-    int n = cap < 7 ? cap : 7;
+    int n = cap < 8 ? cap : 8;
     for (int i = 0; i < n; i++) out[i] = c->counters[i];
     return n;
 }

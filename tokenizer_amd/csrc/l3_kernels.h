@@ -58,6 +58,9 @@ struct SlowEntry {
     uint64_t pool_off;   // first token in the slow pool
 };
 constexpr uint64_t kEntrySequential = 1ull << 63;
+constexpr uint64_t kEntryExpanded = 1ull << 62;   // ... and its symbols are written out: `start` = their offset in the scratch, the
+                                                  // second pass of slow_kernel takes its windows one item each
+constexpr uint64_t kEntryWinMask = ~(kEntrySequential | kEntryExpanded);
 // A long pre-token is worked on in windows of kWin symbols, one work item each (slow_kernel).
 struct WinItem { uint32_t entry, k; };
 
@@ -71,6 +74,8 @@ enum : uint32_t {
     kOvfMiss = 32,     // more short deferred pre-tokens than miss_cap
     kOvfWin = 64,      // more window items than win_cap
     kTooLong = 128,    // a single pre-token of 2 GiB or more
+    kSeqPending = 512,    // long pre-tokens with invalid UTF-8 were only expanded: the host runs slow_kernel's second pass over their windows
+    kGiantPending = 256,  // pieces were left to the grid-wide merge (Workspace::giants): the host runs it, then the tail of the pipeline
 };
 constexpr uint32_t kRetryFlags = kOvfSlow | kOvfPool | kOvfScratch | kOvfMiss | kOvfWin;   // the host grows a list and runs the batch again
 constexpr uint32_t kFatalFlags = kBadOffsets | kTooLong;
@@ -93,7 +98,33 @@ struct Status {
     // launch take it a few entries at a time, do the entries of known, moderate length themselves and prepare the others
     // (end, room in the pool, window items).  slow_q: over the window items (count of them); slow_kernel's workgroups
     // take those one at a time.
-    struct alignas(128) Queue { uint32_t next, count; } slow_q, mid_q;
+    struct alignas(128) Queue { uint32_t next, count; } slow_q, mid_q, seq_q;
+    // pieces left to the grid-wide merge: their number (may exceed kMaxGiants: the surplus was merged by one workgroup each)
+    struct alignas(128) GiantCount { uint32_t count, pad; } giant;
+};
+// A piece of a long pre-token that no cut divides and that is too long for one workgroup (one character repeated a million
+// times, a DNA string): merged by the whole GPU, all such pieces of a batch as ONE flat sequence (giant_* kernels).
+constexpr uint32_t kGiantMin = 32768;    // symbols from which a piece takes that path
+constexpr uint32_t kMaxGiants = 1024;
+struct Giant {
+    const uint8_t* sp;   // symbol bytes of its pre-token (the text, or the expanded copy in the scratch)
+    uint64_t q;          // its first symbol
+    uint32_t n;          // its symbols; 0: open end, looked up in win_first by giant_order_kernel
+    uint32_t entry;      // slow entry of its pre-token
+    uint32_t k, pad;     // window that owns it
+    uint64_t flat;       // its place in the flat sequence (giant_order_kernel)
+    int32_t* img;        // image of its pre-token (slot of symbol i: img[i])
+    uint32_t* live;      // window counters of its pre-token
+};
+constexpr int kGiantGrid = 1024, kGiantThreads = 256, kGiantWaves = kGiantGrid * kGiantThreads / 64;
+struct GiantSeg { uint32_t cnt, open; };
+struct GiantState {
+    uint32_t n, n_next, round, done;
+    unsigned long long best, best_next, theta;
+    uint32_t n_giants, pad;
+    uint32_t order[kMaxGiants];          // giants sorted by their place in the flat sequence
+    uint32_t wave_live[kGiantWaves];
+    GiantSeg wave_seg[kGiantWaves];
 };
 constexpr int kMissShards = 64;
 // a short deferred pre-token (input of merge_kernel).  Its result is one word of miss_res: bits 0..7 = n tokens;
@@ -135,8 +166,12 @@ struct Workspace {
     int32_t* pool;          // [kMissShards * mpool_shard_cap + pool_cap]: results of more than kMissInline tokens of the
                             // merge kernel, one part per shard, then the tokens of the slow pre-tokens
     uint8_t* scratch;       // [scratch_cap] symbol arrays of pre-tokens too long for LDS
+    uint32_t allow_giants;  // 0: no piece is left to the grid-wide merge (the allocation-free entry point: that path allocates)
+    Giant* giants;          // [kMaxGiants]
+    GiantState* gstate;
     WinItem* win;           // [win_cap] window items of the long pre-tokens
     uint32_t* win_live;     // [win_cap] tokens in the image slots of each window's range
+    uint32_t* win_first;    // [win_cap] symbol position of the first cut inside each window, 0xFFFFFFFF: none
     Status* status;
     uint64_t slow_cap, miss_shard_cap, mpool_shard_cap, pool_cap, scratch_cap, win_cap;
 };
@@ -163,6 +198,17 @@ enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvEmit, kEvC
 // the caller enlarged the output buffer).
 hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream,
                          hipEvent_t* ev, bool emit_only);
+// Second pass of slow_kernel (clears kSeqPending first): the windows of the long pre-tokens with invalid UTF-8 that the
+// first pass expanded.
+hipError_t launch_slow_second_pass(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream);
+// The tail of the pipeline again (block totals + finish, scan, emit): after the grid-wide merge of the giant pieces.
+hipError_t launch_encode_tail(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
+// Grid-wide merge of the pieces listed in W.giants (n_giants of them, n_syms symbols in all); `flat` = 24 * n_syms bytes.
+// launch_giants_order: ends of the pieces listed with an open end, their places in the flat sequence; GiantState::n = n_syms.
+hipError_t launch_giants_order(const Workspace& W, uint32_t n_giants, hipStream_t stream);
+hipError_t launch_giants_init(const Tables& T, const Workspace& W, uint32_t n_giants, uint64_t n_syms, void* flat, hipStream_t stream);
+hipError_t launch_giants_rounds(const Tables& T, const Workspace& W, uint64_t n_syms, void* flat, int rounds, hipStream_t stream);
+hipError_t launch_giants_store(const Workspace& W, uint64_t n_syms, void* flat, hipStream_t stream);
 // The second half of the final scatter, for the tiles the fast emit kernel flagged (Status::generic_tiles > 0).
 hipError_t launch_emit_generic(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
 // Decode: ids -> bytes (tokenizer.go:339-354).  Two passes: lengths+scan, then copy.

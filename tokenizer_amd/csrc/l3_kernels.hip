@@ -1759,6 +1759,8 @@ __device__ void mid_pass(const Tables& T, const Workspace& W, const EncodeArgs& 
 constexpr int kWinExam = kWin + kWinBack;                 // positions whose match length a window item computes
 constexpr int kWinPer = kWinExam / kSlowThreads;          // ... consecutive ones per thread
 constexpr int kWinAhead = kMaxTokenBytes;                 // a match looks at most this far ahead
+constexpr int kSeqInline = 8;                             // windows up to which a pre-token with invalid UTF-8 is finished by the item that expands it
+constexpr int kTailSteps = 4;                             // steps of kSlowThreads positions a window walks on to find the end of its last piece
 static_assert(kWinPer * kSlowThreads == kWinExam && kWinPer <= 16 && kWinBack >= kMaxTokenBytes, "window geometry");
 static_assert(kWin >= 2 * kLaneMax, "a lane piece reaches at most into the next window's slots");
 struct PieceLds {
@@ -1858,7 +1860,8 @@ struct SlowShared {
 // One window: symbols [k * kWin, (k + 1) * kWin) of the L symbol bytes `sp` of a pre-token whose image is `img` and
 // whose window counters are live[0 ..].  Whole workgroup.  Returns (uniformly) the number of tokens it wrote.
 __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace& W, const SlowShared& H, const uint8_t* sp, uint32_t L,
-                                                uint32_t k, int32_t* img, uint32_t* live, const uint8_t* buf_lo, const uint8_t* buf_hi) {
+                                                uint32_t k, int32_t* img, uint32_t* live, const uint8_t* buf_lo, const uint8_t* buf_hi,
+                                                uint32_t entry, uint32_t* first) {
     SlowLds& S = *H.S;
     PieceLds& P = *H.P;
     const int tid = threadIdx.x;
@@ -1999,17 +2002,37 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
         while (c) { const int j = __builtin_ctz(c); c &= c - 1; P.pl[kk++] = (uint16_t)(p0 + (uint32_t)j); }
     }
     __syncthreads();
+    if (tid == 0) first[k] = k_total ? o0 + (uint32_t)P.pl[0] : 0xFFFFFFFFu;   // (for pieces whose end is looked up later)
     if (k_total == 0) return 0;   // (uniform) the whole window lies inside a piece that started earlier
 #if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 1
     return 0;
 #endif
     // where the last piece ends: at the end of the pre-token, at the window's end if that is a cut, else at the first cut
-    // behind it -- found by walking on, one position per thread and step
+    // behind it -- found by walking on, one position per thread and step.  After kTailSteps steps without a cut the
+    // piece is LISTED for the grid-wide merge with its end left open (the later windows record their first cuts:
+    // Workspace::win_first) -- walking a million blanks this way would take a hundred milliseconds.
     uint32_t last_end = n_ex;      // window-local, may lie far beyond the window
+    bool last_deferred = false;
     if (hi < L && all > n_ex) {
         uint32_t carry = all;      // furthest reach of all positions before `pos` (window-local)
         uint32_t pos = n_ex;
-        for (;;) {
+        for (uint32_t step = 0;; step++) {
+            if (step == (uint32_t)kTailSteps && W.allow_giants) {
+                __syncthreads();
+                if (tid == 0) {
+                    const uint32_t g = atomicAdd(&W.status->giant.count, 1u);
+                    H.lvars[6] = 0;
+                    if (g < kMaxGiants) {
+                        Giant G;
+                        G.sp = sp; G.q = (uint64_t)o0 + P.pl[k_total - 1u]; G.n = 0; G.entry = entry; G.k = k; G.flat = 0; G.img = img; G.live = live;
+                        W.giants[g] = G;
+                        atomicOr(&W.status->flags, kGiantPending);
+                        H.lvars[6] = 1;
+                    }
+                }
+                __syncthreads();
+                if (H.lvars[6]) { last_deferred = true; break; }   // (uniform; a full list: walk on)
+            }
             const uint32_t p = pos + (uint32_t)tid;
             const uint32_t pa = o0 + p;   // symbol position
             uint32_t r = 0;
@@ -2048,14 +2071,15 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
     return 0;
 #endif
     const uint32_t range_hi = lo + (uint32_t)kWin;   // slots from here on belong to the next window's counter
-    const bool whole_single = k_total == 1 && lo == 0 && last_end == L;   // the pre-token is one piece (o0 == 0)
+    const bool whole_single = !last_deferred && k_total == 1 && lo == 0 && last_end == L;   // the pre-token is one piece (o0 == 0)
+    const uint32_t n_pieces = last_deferred ? k_total - 1u : k_total;   // (the listed one is not this kernel's any more)
     uint32_t own_cnt = 0, nxt_cnt = 0, long_cnt = 0;
     // single symbols need no merge: their token goes straight to the image; the others are listed
     uint32_t n_multi = 0;
 #pragma unroll 1
-    for (uint32_t i0 = 0; i0 < k_total; i0 += kSlowThreads) {
+    for (uint32_t i0 = 0; i0 < n_pieces; i0 += kSlowThreads) {
         const uint32_t i = i0 + (uint32_t)tid;
-        const bool have = i < k_total;
+        const bool have = i < n_pieces;
         const uint32_t s = have ? P.pl[i] : 0u;
         const uint32_t e = have ? (i + 1 < k_total ? (uint32_t)P.pl[i + 1] : last_end) : 0u;
         const bool multi = have && (e - s >= 2 || whole_single);
@@ -2150,6 +2174,22 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
                     const uint32_t pi = P.ml[i0 + w2 * 64u + b];
                     const uint32_t ps = P.pl[pi], pe = pi + 1 < k_total ? (uint32_t)P.pl[pi + 1] : last_end;
                     const uint64_t pq0 = (uint64_t)o0 + ps;
+                    if (pe - ps >= kGiantMin && W.allow_giants) {   // too long for one workgroup: listed for the grid-wide merge (if the list has room)
+                        __syncthreads();
+                        if (tid == 0) {
+                            const uint32_t g = atomicAdd(&W.status->giant.count, 1u);
+                            H.lvars[6] = 0;
+                            if (g < kMaxGiants) {
+                                Giant G;
+                                G.sp = sp; G.q = pq0; G.n = pe - ps; G.entry = entry; G.k = k; G.flat = 0; G.img = img; G.live = live;
+                                W.giants[g] = G;
+                                atomicOr(&W.status->flags, kGiantPending);
+                                H.lvars[6] = 1;
+                            }
+                        }
+                        __syncthreads();
+                        if (H.lvars[6]) continue;   // (uniform)
+                    }
                     const uint32_t n_out = rounds_piece(T, W, S, sp, pq0, pe - ps, whole_single, img, H.tmp, H.tmp64, H.segtmp, H.lvars, H.xb);
                     long_cnt += n_out;
                     if (tid == 0) {   // its tokens may lie in the slots of several windows
@@ -2187,7 +2227,7 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
 #ifndef L3_SLOW_OCC
 #define L3_SLOW_OCC 1
 #endif
-__global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables T, Workspace W, EncodeArgs A) {
+__global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables T, Workspace W, EncodeArgs A, int pass) {
     __shared__ __align__(16) SlowLds S;
     __shared__ __align__(16) PieceLds P;
     __shared__ uint8_t byte_tok[256];
@@ -2210,7 +2250,7 @@ __global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables 
 #pragma unroll 1
     for (;;) {
         __syncthreads();
-        if (tid == 0) ivars[1] = first ? (int)blockIdx.x : (int)(gridDim.x + atomicAdd(&W.status->slow_q.next, 1u));
+        if (tid == 0) ivars[1] = first ? (int)blockIdx.x : (int)(gridDim.x + atomicAdd(pass ? &W.status->seq_q.next : &W.status->slow_q.next, 1u));
         first = false;
         __syncthreads();
         if ((uint32_t)ivars[1] >= n_items) break;
@@ -2220,15 +2260,28 @@ __global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables 
         const uint32_t len = W.slow[ei].len;
         const uint64_t win0 = W.slow[ei].win0;
         const bool sequential = (win0 & kEntrySequential) != 0;
-        uint32_t* const live = W.win_live + (win0 & ~kEntrySequential);
+        uint32_t* const live = W.win_live + (win0 & kEntryWinMask);
+        uint32_t* const first = W.win_first + (win0 & kEntryWinMask);
         const uint64_t slots = sequential ? 3ull * len : (uint64_t)len;
         int32_t* const img = W.pool + W.slow[ei].pool_off + slots;   // the image lies behind the room for the final tokens
         uint32_t total = 0;
+        if (pass) {   // second pass: the windows of the pre-tokens the first pass expanded, one item each
+            if (!(win0 & kEntryExpanded)) continue;
+            const uint32_t L = W.slow[ei].pad;
+            if ((uint64_t)it.k * (uint64_t)kWin >= (uint64_t)L) continue;
+            const uint8_t* xs = W.scratch + start;
+            total = window_work(T, W, H, xs, L, it.k, img, live, xs, xs + (((uint64_t)L + 31ull) & ~15ull), ei, first);
+            if (tid == 0 && total) {
+                atomicAdd(&W.slow[ei].count, total);
+                atomicAdd(&W.tile_extra[W.slow[ei].tile], total);   // (the first pass has taken the one off)
+            }
+            continue;
+        }
         if (!sequential) {
-            total = window_work(T, W, H, A.text + start, len, it.k, img, live, A.text, A.text + A.n_bytes);
+            total = window_work(T, W, H, A.text + start, len, it.k, img, live, A.text, A.text + A.n_bytes, ei, first);
             if (tid == 0 && it.k == 0) W.slow[ei].pad = len;   // its symbols
         } else {
-            if (it.k != 0) continue;   // one item works through all the windows of a pre-token with invalid UTF-8
+            if (it.k != 0) continue;   // a pre-token with invalid UTF-8: ONE item expands it
             // symbols: one per byte, EF BF BD for a byte that is not valid UTF-8 (state_machine.go:36), written out
             // to the scratch; every wave takes one contiguous range of the bytes, 64 at a time (order by ballots)
             GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
@@ -2277,13 +2330,23 @@ __global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables 
             }
             __syncthreads();
             const uint32_t nw = (L + (uint32_t)kWin - 1) / (uint32_t)kWin;
+            if (nw > (uint32_t)kSeqInline && W.allow_giants) {
+                // many windows: left to the second pass, where every window is an item of its own (the host starts it)
+                if (tid == 0) {
+                    W.slow[ei].start = (uint64_t)lvars[5];
+                    W.slow[ei].win0 = win0 | kEntryExpanded;
+                    W.slow[ei].pad = L;
+                    atomicOr(&W.status->flags, kSeqPending);
+                }
+            } else
 #pragma unroll 1
-            for (uint32_t kk = 0; kk < nw; kk++) total += window_work(T, W, H, xs, L, kk, img, live, xs, xs + (((uint64_t)L + 31ull) & ~15ull));
-            if (tid == 0) W.slow[ei].pad = L;
+            for (uint32_t kk = 0; kk < nw; kk++) total += window_work(T, W, H, xs, L, kk, img, live, xs, xs + (((uint64_t)L + 31ull) & ~15ull), ei, first);
+            if (tid == 0) W.slow[ei].pad = L;   // (the same value if it was left to the second pass)
         }
-        if (tid == 0 && total) {
+        if (tid == 0 && (total || it.k == 0)) {
             atomicAdd(&W.slow[ei].count, total);
-            // tile_extra counts the tokens beyond the one the pre-token's stream item stands for
+            // tile_extra counts the tokens beyond the one the pre-token's stream item stands for (modulo 2^32: the tokens
+            // of a giant piece are added later)
             atomicAdd(&W.tile_extra[W.slow[ei].tile], total - ((it.k == 0) ? 1u : 0u));
         }
     }
@@ -2297,7 +2360,7 @@ __device__ void finish_window(const Workspace& W, uint32_t w, unsigned long long
     const int tid = threadIdx.x;
     const WinItem it = W.win[w];
     const uint64_t win0 = W.slow[it.entry].win0;
-    const uint32_t* live = W.win_live + (win0 & ~kEntrySequential);
+    const uint32_t* live = W.win_live + (win0 & kEntryWinMask);
     const uint32_t mine = live[it.k];
     if (mine == 0) return;   // (uniform)
     const uint32_t len = W.slow[it.entry].len, L = W.slow[it.entry].pad;
@@ -2351,7 +2414,7 @@ static_assert(kFinishThreads == kScanBlock, "finish_window runs in block_totals_
 // images to their final place (same launch: both only need what the kernels before have left).
 __global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, uint64_t n_tiles, uint64_t n_docs, uint32_t n_blocks) {
     __shared__ unsigned long long wsum[kScanBlock / 64];
-    if (W.status->flags & kFatalFlags) return;
+    if (W.status->flags & (kFatalFlags | kGiantPending | kSeqPending)) return;
     if (blockIdx.x >= n_blocks) {
         if (W.status->flags & kRetryFlags) return;
         const uint32_t n_items = W.status->slow_q.count;
@@ -2389,7 +2452,7 @@ __global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, u
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeArgs A, uint64_t n_blocks) {
     __shared__ unsigned long long wsum[kScanThreads / 64];
     __shared__ unsigned long long carry_s;
-    if (W.status->flags & kBadOffsets) return;
+    if (W.status->flags & (kBadOffsets | kGiantPending | kSeqPending)) return;
     const int tid = threadIdx.x;
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -2496,7 +2559,7 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
     const unsigned long long blk_base = W.tile_base[tile / kScanBlock];
     const uint32_t fl = W.status->flags;
     const unsigned long long total_tokens = W.status->total_tokens;
-    if (fl & (kFatalFlags | kRetryFlags)) return;
+    if (fl & (kFatalFlags | kRetryFlags | kGiantPending | kSeqPending)) return;
     if (total_tokens > A.out_cap) return;
     const uint32_t n_items = rec.n_items;
     const uint64_t n_tok = (uint64_t)n_items + rec.n_extra;
@@ -2703,7 +2766,7 @@ __global__ __launch_bounds__(kTileThreads) void emit_generic_kernel(Workspace W,
     __shared__ int32_t q_item[kEmitQueue];
     __shared__ uint32_t q_n;
     const uint32_t fl = W.status->flags;
-    if (fl & (kFatalFlags | kRetryFlags)) return;
+    if (fl & (kFatalFlags | kRetryFlags | kGiantPending | kSeqPending)) return;
     if (W.status->total_tokens > A.out_cap) return;
     const uint64_t t0 = (uint64_t)blockIdx.x * kGenericPer;
     for (uint64_t t = t0; t < t0 + kGenericPer && t < n_tiles; t++) {
@@ -2813,6 +2876,43 @@ hipError_t launch_emit_generic(const Workspace& W, const EncodeArgs& A, hipStrea
     return hipSuccess;
 }
 
+#ifndef L3_FINISH_GRID
+#define L3_FINISH_GRID 512
+#endif
+#ifndef L3_SLOW_GRID
+#define L3_SLOW_GRID 512
+#endif
+static hipError_t launch_totals_scan(const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
+    const uint64_t n_tiles = num_tiles(A.n_bytes);
+    const uint64_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks + L3_FINISH_GRID), dim3(kScanBlock), 0, stream, W, n_tiles, A.n_docs,
+                       (uint32_t)n_blocks);
+    L3_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, W, A, n_blocks);
+    L3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+__global__ void status_and_kernel(Status* st, uint32_t mask) { st->flags &= mask; }
+
+hipError_t launch_slow_second_pass(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
+    hipLaunchKernelGGL(status_and_kernel, dim3(1), dim3(1), 0, stream, W.status, ~(uint32_t)kSeqPending);
+    L3_LAUNCH_CHECK();
+    uint64_t sgrid = W.slow_cap < L3_SLOW_GRID ? W.slow_cap : L3_SLOW_GRID;
+    if (sgrid == 0) sgrid = 1;
+    hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A, 1);
+    L3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_encode_tail(const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
+    hipError_t e_ = launch_totals_scan(W, A, stream);
+    if (e_ != hipSuccess) return e_;
+    hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)num_tiles(A.n_bytes)), dim3(kTileThreads), 0, stream, W, A);
+    L3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream, hipEvent_t* ev,
                          bool emit_only) {
     const uint64_t n_tiles = num_tiles(A.n_bytes);
@@ -2845,18 +2945,11 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
             L3_LAUNCH_CHECK();
         }
         L3_EV(kEvMerge);
-        hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A);
+        hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A, 0);
         L3_LAUNCH_CHECK();
         L3_EV(kEvSlow);
-        const uint64_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
-#ifndef L3_FINISH_GRID
-#define L3_FINISH_GRID 512
-#endif
-        hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks + L3_FINISH_GRID), dim3(kScanBlock), 0, stream, W, n_tiles, A.n_docs,
-                           (uint32_t)n_blocks);
-        L3_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, W, A, n_blocks);
-        L3_LAUNCH_CHECK();
+        hipError_t e2_ = launch_totals_scan(W, A, stream);
+        if (e2_ != hipSuccess) return e2_;
         L3_EV(kEvScan);
     }
     hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)n_tiles), dim3(kTileThreads), 0, stream, W, A);

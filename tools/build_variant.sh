@@ -9,6 +9,7 @@ mkdir -p ../lib/variants ../lib/obj
 HIPCC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -I../../include"
 $HIPCC $2 -c -o ../lib/variants/k_$1.o l3_kernels.hip
 $HIPCC $2 -c -o ../lib/variants/a_$1.o l3_api.hip
+$HIPCC $2 -c -o ../lib/variants/g_$1.o l3_giant.hip
 make -s ../lib/obj/l3_tables.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libl3hip_$1.so ../lib/variants/a_$1.o ../lib/variants/k_$1.o ../lib/obj/l3_tables.o
-rm -f ../lib/variants/k_$1.o ../lib/variants/a_$1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libl3hip_$1.so ../lib/variants/a_$1.o ../lib/variants/k_$1.o ../lib/variants/g_$1.o ../lib/obj/l3_tables.o
+rm -f ../lib/variants/k_$1.o ../lib/variants/a_$1.o ../lib/variants/g_$1.o
