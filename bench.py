@@ -8,8 +8,8 @@ One process per GPU.  Started plainly with --gpus N > 1 it launches N fresh rank
 
 Workload: the C5 corpus of SURVEY.md 8(d) -- 67,108,864 synthetic English documents of 1,024 B, document i generated from
 seed + i ON the GPU that owns it (tools/l3_corpus_dev.hip; the same bytes as the host generator) -- cut into batches of
-65,536 documents (64 MiB = the C2 configuration of BASELINE.json).  A step = one l3_encode_batch_device call over one
-batch: text resident in HBM, token ids and per-document offsets left in HBM; every step encodes a DIFFERENT batch.
+65,536 documents (64 MiB = the C2 configuration of BASELINE.json).  A step = one batch through l3_encode_submit / l3_encode_wait
+(the stream-ordered halves of l3_encode_batch_device; the wait of batch k follows the submit of batch k + 1): text resident in HBM, token ids and per-document offsets left in HBM; every step encodes a DIFFERENT batch.
 
   --config c2 (default)  K steps per rank: rank r's step s is batch s * N + r of the corpus.  Weak scaling (per-GPU work
                          is fixed as N grows).  This is the headline line: `value` = tokens of all ranks / max time.
@@ -173,23 +173,47 @@ def main():
     d_out_off = torch.empty(n_docs + 1, dtype=torch.int64, device="cuda")
     flags = capi.L3_BOS | capi.L3_EOS
 
-    # the call of one step, with its arguments marshalled once: the host side of a step is in the timed region too
+    # The calls of one step, with their arguments marshalled once (the host side of a step is in the timed region too).
+    # A step = l3_encode_submit of its batch + l3_encode_wait of the batch before: the host looks at batch k while the
+    # GPU is busy with batch k + 1 (two output buffers in turn), as the loop of a corpus job does.
     n_out = C.c_uint64(0)
-    encode = ctx.lib.l3_encode_batch_device
+    ticket = C.c_int(-1)
     base_ptr = d_text.data_ptr()
+    d_out2 = torch.empty(out_cap, dtype=torch.int32, device="cuda")
+    d_out_off2 = torch.empty(n_docs + 1, dtype=torch.int64, device="cuda")
+    outs = ((d_out, d_out_off), (d_out2, d_out_off2))
 
-    def call_args(i):
+    def submit_args(i):
+        o, oo = outs[i & 1]
         return (ctx.h, C.c_void_p(base_ptr + i * n_bytes), C.c_uint64(n_bytes), C.c_void_p(d_off.data_ptr()), C.c_uint64(n_docs),
-                C.c_uint32(flags), C.c_void_p(d_out.data_ptr()), C.c_uint64(out_cap), C.c_void_p(d_out_off.data_ptr()),
-                C.byref(n_out), None)
+                C.c_uint32(flags), C.c_void_p(o.data_ptr()), C.c_uint64(out_cap), C.c_void_p(oo.data_ptr()), None, C.byref(ticket))
 
-    all_args = [call_args(i) for i in range(steps)]
+    all_args = [submit_args(i) for i in range(steps)]
+    submit_fn, wait_fn = ctx.lib.l3_encode_submit, ctx.lib.l3_encode_wait
 
-    def step(i):
-        rc = encode(*all_args[i])
+    def submit(i):
+        rc = submit_fn(*all_args[i])
         if rc != capi.L3_OK:
-            raise RuntimeError("l3_encode_batch_device failed: %d" % rc)
+            raise RuntimeError("l3_encode_submit failed: %d" % rc)
+        return ticket.value
+
+    def wait(t):
+        rc = wait_fn(ctx.h, t, C.byref(n_out))
+        if rc != capi.L3_OK:
+            raise RuntimeError("l3_encode_wait failed: %d" % rc)
         return n_out.value
+
+    def run(first, count):
+        """batches first .. first + count, one pending while the next is queued; returns their token total"""
+        total, prev = 0, None
+        for i in range(first, first + count):
+            t = submit(i)
+            if prev is not None:
+                total += wait(prev)
+            prev = t
+        if prev is not None:
+            total += wait(prev)
+        return total
 
     def sync():
         if dist is not None:
@@ -197,14 +221,11 @@ def main():
         torch.cuda.synchronize()
 
     ctx.set_profiling(True)   # HIP events on the launch stream around every kernel of every call
-    for i in range(len(warm_batches)):
-        step(i)
+    run(0, len(warm_batches))
     sync()
     ctx.set_profiling(True)   # resets the library's per-kernel sums: they cover exactly the timed steps
     t0 = time.perf_counter()
-    n_tok_total = 0
-    for i in range(steps):
-        n_tok_total += step(i)
+    n_tok_total = run(0, steps)
     sync()
     dt = time.perf_counter() - t0
     kern, n_prof = ctx.timing_totals()
@@ -310,7 +331,7 @@ def main():
             for _ in range(passes):  # one tokenizer, its pre-token caches persist as the reference's default cache does
                 exp_tok, exp_off = oracle.encode_batch(s_text, s_off, True, True, threads=threads)
             cdt = time.perf_counter() - c0
-            step(0)
+            wait(submit(0))
             torch.cuda.synchronize()
             got_off = d_out_off[:ns + 1].cpu().numpy().astype(np.uint64)
             got_tok = d_out[:int(got_off[-1])].cpu().numpy()

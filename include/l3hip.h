@@ -60,6 +60,19 @@ int l3_encode_batch_device(l3_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes,
                            uint64_t n_docs, uint32_t flags, int32_t* d_out_tok, uint64_t out_cap,
                            uint64_t* d_out_off, uint64_t* n_tok, void* stream);
 
+/* l3_encode_batch_device as two stream-ordered halves (NO COUNTERPART IN THE REFERENCE, whose Encode is a plain function
+ * call): l3_encode_submit queues the whole pipeline of one batch on `stream` and returns without waiting; l3_encode_wait
+ * waits for that batch and returns what l3_encode_batch_device returns (*n_tok, L3_E_OUTPUT_CAP with the size needed, ...).
+ * A caller that submits batch k + 1 before it waits for batch k keeps the GPU busy while the host looks at a result: the
+ * loop of a corpus job (bench.py).  Up to L3_MAX_PENDING batches may be pending on a context; they are executed in
+ * submission order (they share the context's workspace), each needs its own output buffers, and all buffers of a batch
+ * must stay valid until its wait has returned.  A batch that turns out to need a larger workspace or one of the
+ * host-driven passes (very long pre-tokens) is run again, synchronously, inside its l3_encode_wait. */
+#define L3_MAX_PENDING 4
+int l3_encode_submit(l3_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+                     uint32_t flags, int32_t* d_out_tok, uint64_t out_cap, uint64_t* d_out_off, void* stream, int* ticket);
+int l3_encode_wait(l3_ctx* ctx, int ticket, uint64_t* n_tok);
+
 /* l3_encode_batch_device for callers that must not allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
  * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
  * arguments, results and error codes as l3_encode_batch_device, but its workspace (intermediate items, deferred pre-token

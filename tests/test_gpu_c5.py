@@ -117,3 +117,72 @@ def test_one_call_over_more_than_2_31_bytes(ctx, oracle):
         lo, hi = int(off[first]), int(off[first + 600])
         assert hi - lo == exp_tok.size and np.array_equal(d_out[lo:hi].cpu().numpy(), exp_tok)
         assert np.array_equal((off[first:first + 601] - lo).astype(np.uint64), exp_off)
+
+
+def test_submit_wait_pipeline(ctx, oracle):
+    """l3_encode_submit / l3_encode_wait: up to four batches pending on one context, waited for in and out of order,
+    every batch with its own output buffers; one of them holds a giant pre-token and documents with invalid UTF-8 (its
+    wait runs it again synchronously), one is empty, one reports a too small output buffer."""
+    import torch
+    from tokenizer_amd import capi
+    from tests import corpus
+    import random
+    rng = random.Random(5)
+    batches = []
+    for b in range(7):
+        if b == 3:
+            docs = [b"a" * 200000, b"\xff" * 30000, b"tail"] + [corpus.random_doc(rng, max_pieces=20) for _ in range(50)]
+            text, off = capi.pack_docs(docs)
+        elif b == 5:
+            text, off = capi.pack_docs([])
+        else:
+            text, off = corpora.english(4096 + 512 * b, DOC, first_doc=77000 * b)
+        batches.append((text, off))
+    dev = []
+    for text, off in batches:
+        d_text = torch.from_numpy(np.ascontiguousarray(text)).cuda() if text.size else torch.zeros(16, dtype=torch.uint8, device="cuda")
+        d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+        cap = int(text.size) * 3 + 2 * (off.size - 1) + 16
+        dev.append((d_text, d_off, torch.full((cap,), -3, dtype=torch.int32, device="cuda"),
+                    torch.full((off.size,), -3, dtype=torch.int64, device="cuda"), cap))
+    torch.cuda.synchronize()
+
+    def submit(i, cap=None):
+        d_text, d_off, d_out, d_oo, c = dev[i]
+        rc, t = ctx.encode_submit(d_text.data_ptr(), int(batches[i][0].size), d_off.data_ptr(), batches[i][1].size - 1, 3,
+                                  d_out.data_ptr(), c if cap is None else cap, d_oo.data_ptr(), None)
+        assert rc == capi.L3_OK, ctx._err(rc)
+        return t
+
+    def check(i, t):
+        rc, n = ctx.encode_wait(t)
+        assert rc == capi.L3_OK, ctx._err(rc)
+        exp_tok, exp_off = oracle.encode_batch(batches[i][0], batches[i][1], True, True, threads=8)
+        assert n == exp_tok.size
+        assert np.array_equal(dev[i][2][:n].cpu().numpy(), exp_tok)
+        assert np.array_equal(dev[i][3].cpu().numpy().astype(np.uint64), exp_off)
+
+    t0, t1, t2, t3 = submit(0), submit(1), submit(2), submit(3)
+    rc, _ = ctx.encode_submit(dev[4][0].data_ptr(), int(batches[4][0].size), dev[4][1].data_ptr(), batches[4][1].size - 1, 3,
+                              dev[4][2].data_ptr(), dev[4][4], dev[4][3].data_ptr(), None)
+    assert rc == capi.L3_E_INVALID_ARG                       # a fifth pending batch is refused
+    check(1, t1)                                             # out of order
+    t4 = submit(4)
+    check(0, t0)
+    check(3, t3)                                             # the giant: run again inside its wait
+    t5 = submit(5)
+    check(2, t2)
+    t6 = submit(6, cap=100)                                  # too small an output buffer
+    check(4, t4)
+    check(5, t5)
+    rc, need = ctx.encode_wait(t6)
+    exp_tok, _ = oracle.encode_batch(batches[6][0], batches[6][1], True, True, threads=8)
+    assert rc == capi.L3_E_OUTPUT_CAP and need == exp_tok.size
+    rc, _ = ctx.encode_wait(t6)
+    assert rc == capi.L3_E_INVALID_ARG                       # nothing pending under that ticket any more
+    # the synchronous call still works on the same context, and with a batch pending
+    t = submit(0)
+    rc, n = ctx.encode_batch_device(dev[1][0].data_ptr(), int(batches[1][0].size), dev[1][1].data_ptr(), batches[1][1].size - 1, 3,
+                                    dev[1][2].data_ptr(), dev[1][4], dev[1][3].data_ptr(), None)
+    assert rc == capi.L3_OK
+    check(0, t)

@@ -35,6 +35,8 @@ SYMBOLS = [
     ("l3_encode_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     ("l3_encode_batch_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P,
                                         C.POINTER(C.c_uint64), _P]),
+    ("l3_encode_submit", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, _P, C.POINTER(C.c_int)]),
+    ("l3_encode_wait", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
     ("l3_encode_batch_device_noalloc", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P,
                                                 C.POINTER(C.c_uint64), _P]),
     ("l3_pretokenize_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P]),
@@ -192,6 +194,19 @@ class Context:
         n = C.c_uint64(0)
         fn = self.lib.l3_encode_batch_device_noalloc if noalloc else self.lib.l3_encode_batch_device
         rc = fn(self.h, d_text_ptr, n_bytes, d_off_ptr, n_docs, flags, d_out_ptr, out_cap, d_out_off_ptr, C.byref(n), stream)
+        return rc, int(n.value)
+
+    def encode_submit(self, d_text_ptr, n_bytes, d_off_ptr, n_docs, flags, d_out_ptr, out_cap, d_out_off_ptr, stream=None):
+        """Stream-ordered first half (l3_encode_submit).  Returns (rc, ticket)."""
+        t = C.c_int(-1)
+        rc = self.lib.l3_encode_submit(self.h, d_text_ptr, n_bytes, d_off_ptr, n_docs, flags, d_out_ptr, out_cap, d_out_off_ptr,
+                                       stream, C.byref(t))
+        return rc, t.value
+
+    def encode_wait(self, ticket):
+        """Second half (l3_encode_wait).  Returns (rc, n_tok)."""
+        n = C.c_uint64(0)
+        rc = self.lib.l3_encode_wait(self.h, ticket, C.byref(n))
         return rc, int(n.value)
 
     # ---- small queries ------------------------------------------------------------------------------

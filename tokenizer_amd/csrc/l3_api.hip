@@ -75,12 +75,13 @@ struct l3_ctx {
     HostTables H;
     Tables T{};
     DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes, t_prefix2, t_bloom;
-    // The status word is cleared AFTER a call has read it back (so the clear runs between two calls, not in front of the
-    // kernels).  The clear is ordered before the next call's kernels by an event the context owns: the caller's stream
-    // handle is never kept, it may be destroyed between two calls.
-    bool clear_pending = false;       // a clear of w_status has been queued and ev_clear recorded behind it
-    bool clear_on_own = false;        // ... on the context's own stream (same-stream order makes the wait unnecessary)
-    hipEvent_t ev_clear = nullptr;
+    // The status word is zero between two calls: the kernel that hands it to the host (status_out_kernel) clears it, in
+    // stream order behind the batch.  Calls on DIFFERENT streams are ordered by an event the context owns, recorded behind
+    // every batch: the caller's stream handle is never kept, it may be destroyed between two calls.
+    bool status_dirty = false;        // a call ended (with an error) between two host-driven passes: the word is zeroed first
+    bool order_pending = false;       // ev_order has been recorded behind the last batch
+    bool order_on_own = false;        // ... on the context's own stream (same-stream order makes the wait unnecessary)
+    hipEvent_t ev_order = nullptr;
     DevBuf w_arena, w_status;         // the per-call workspace (one block, carve_workspace) and the status word
     DevBuf w_giant;                   // flat arrays of the grid-wide merge of giant pieces (only batches that have such pieces)
     DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
@@ -100,6 +101,16 @@ struct l3_ctx {
     double sum_ms[kEvCount] = {};     // over the profiled calls since profiling was switched on
     uint64_t sum_calls = 0;
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // stream-ordered calls (l3_encode_submit / l3_encode_wait): what each pending batch left for its wait
+    struct Pending {
+        bool in_use = false, made = false, profiled = false;
+        EncodeArgs A{};
+        hipStream_t stream = nullptr;
+        Status* h_status = nullptr;   // pinned
+        hipEvent_t done = nullptr;
+        hipEvent_t ev[kEvCount] = {};
+    } pend[L3_MAX_PENDING];
+    int n_pending = 0;
     std::unordered_map<std::string, int> special_by_name;
     std::mutex mu;
     std::string err;
@@ -242,24 +253,37 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     return L3_OK;
 }
 
-// Queues the clear of the status word behind everything on `stream` and records the context's event behind it.
-int queue_status_clear(l3_ctx* c, const Workspace& W, hipStream_t stream) {
-    HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream));
-    HIPCHK(c, hipEventRecord(c->ev_clear, stream));
-    c->clear_pending = true;
-    c->clear_on_own = stream == c->stream;
+// Orders `stream` behind the last batch of the context (the workspace is shared) ...
+int order_behind_last(l3_ctx* c, hipStream_t stream) {
+    if (c->order_pending) {
+        c->order_pending = false;
+        if (!(c->order_on_own && stream == c->stream)) HIPCHK(c, hipStreamWaitEvent(stream, c->ev_order, 0));
+    }
+    return L3_OK;
+}
+// ... and marks the end of this one
+int mark_batch_end(l3_ctx* c, hipStream_t stream) {
+    if (stream != c->stream) HIPCHK(c, hipEventRecord(c->ev_order, stream));   // (calls on the own stream are ordered anyway)
+    c->order_pending = stream != c->stream;
+    c->order_on_own = false;
     return L3_OK;
 }
 
 // After L3_E_OUTPUT_CAP and a larger output buffer: only the final scatter again.  The scatter counts the tiles it leaves
 // to the generic kernel in the (already cleared) status word, so the word is cleared once more behind it.
 int rerun_emit(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
-    if (c->clear_pending) {
-        c->clear_pending = false;
-        if (!(c->clear_on_own && stream == c->stream)) HIPCHK(c, hipStreamWaitEvent(stream, c->ev_clear, 0));
-    }
+    int rc = order_behind_last(c, stream);
+    if (rc) return rc;
     HIPCHK(c, launch_encode(c->T, W, A, stream, nullptr, true));
-    return queue_status_clear(c, W, stream);
+    HIPCHK(c, launch_status_out(W, c->h_status, stream));
+    return mark_batch_end(c, stream);
+}
+
+// Waits for the batches queued by l3_encode_submit (they share the workspace with every other call on the context).
+int drain_pending(l3_ctx* c) {
+    for (auto& p : c->pend)
+        if (p.in_use) HIPCHK(c, hipEventSynchronize(p.done));
+    return L3_OK;
 }
 
 // Pieces too long for one workgroup were listed by slow_kernel (kGiantPending; the kernels behind it have skipped): the
@@ -289,7 +313,7 @@ int run_giants(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t s
     HIPCHK(c, hipMemsetAsync(&W.status->flags, 0, 8, stream));   // flags (kGiantPending) and generic_tiles
     HIPCHK(c, launch_encode_tail(W, A, stream));
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[kEvEmit], stream));   // the "emit" figure then holds the grid-wide merge too
-    HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, launch_status_out(W, c->h_status, stream));
     HIPCHK(c, hipStreamSynchronize(stream));
     return L3_OK;
 }
@@ -304,25 +328,25 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
     const uint64_t n_tiles = num_tiles(A.n_bytes);
     if (n_tiles > 0x7FFFFFFFull) { c->err = "batch too large: split it"; return L3_E_INVALID_ARG; }
     c->counters[4] = 0;
+    if (c->n_pending) { int rc0 = drain_pending(c); if (rc0) return rc0; }
     for (int attempt = 0;; attempt++) {
         Workspace W{};
         int rc = ensure_workspace(c, A.n_bytes, A.n_docs, W);
         if (rc) return rc;
         // W.status is all zero here: cleared when the context made it and again after every read-back below, so the
         // clear runs while the host is busy between two calls instead of in front of the kernels
-        if (c->clear_pending) {   // (a wait on an event recorded on this same stream is a no-op for the hardware queue)
-            c->clear_pending = false;
-            if (!(c->clear_on_own && stream == c->stream)) HIPCHK(c, hipStreamWaitEvent(stream, c->ev_clear, 0));
-        }
+        if ((rc = order_behind_last(c, stream))) return rc;
+        if (c->status_dirty) { HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream)); c->status_dirty = false; }
         HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false));
-        HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
+        HIPCHK(c, launch_status_out(W, c->h_status, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
+        if (c->h_status->flags & (kSeqPending | kGiantPending)) c->status_dirty = true;   // until a pass below has handed it out cleared
         c->counters[7] = 0;
         bool redo_tail = false;
         if ((c->h_status->flags & kSeqPending) && !(c->h_status->flags & (kFatalFlags | kRetryFlags))) {
             // long pre-tokens with invalid UTF-8 have been expanded: their windows now, in parallel
             HIPCHK(c, launch_slow_second_pass(c->T, W, A, stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
+            HIPCHK(c, launch_status_out(W, c->h_status, stream, 0));   // (its counts are still needed on the device)
             HIPCHK(c, hipStreamSynchronize(stream));
             redo_tail = true;
         }
@@ -330,19 +354,21 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
             const Status st0 = *c->h_status;
             if ((rc = run_giants(c, W, A, stream, st0))) return rc;
             redo_tail = false;
+            c->status_dirty = false;
         }
         if (redo_tail && !(c->h_status->flags & (kFatalFlags | kRetryFlags))) {
             HIPCHK(c, launch_encode_tail(W, A, stream));
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[kEvEmit], stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_status, W.status, sizeof(Status), hipMemcpyDeviceToHost, stream));
+            HIPCHK(c, launch_status_out(W, c->h_status, stream));
             HIPCHK(c, hipStreamSynchronize(stream));
+            c->status_dirty = false;
         }
         if (c->h_status->generic_tiles && !(c->h_status->flags & (kFatalFlags | kRetryFlags | kOvfOut))) {
             // tiles with empty documents or token floods: the generic scatter, launched only when the fast one asks
             HIPCHK(c, launch_emit_generic(W, A, stream));
             HIPCHK(c, hipStreamSynchronize(stream));
         }
-        if ((rc = queue_status_clear(c, W, stream))) return rc;
+        if ((rc = mark_batch_end(c, stream))) return rc;
         const Status st = *c->h_status;
         if (st.flags & kBadOffsets) {
             c->err = "doc_off must start at 0, be ascending and end at n_bytes";
@@ -445,7 +471,7 @@ int l3_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, s
     for (int i = 0; i < kEvCount; i++)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(L3_E_HIP); }
     c->have_events = true;
-    if (hipEventCreateWithFlags(&c->ev_clear, hipEventDisableTiming) != hipSuccess) { c->ev_clear = nullptr; c->err = "hipEventCreate failed"; return fail(L3_E_HIP); }
+    if (hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming) != hipSuccess) { c->ev_order = nullptr; c->err = "hipEventCreate failed"; return fail(L3_E_HIP); }
     if (hipHostMalloc((void**)&c->h_status, sizeof(Status), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_total, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         c->err = "hipHostMalloc failed";
@@ -478,7 +504,14 @@ void l3_destroy(l3_ctx* c) {
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->have_events)
         for (int i = 0; i < kEvCount; i++) (void)hipEventDestroy(c->ev[i]);
-    if (c->ev_clear) (void)hipEventDestroy(c->ev_clear);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
+    for (auto& p : c->pend) {
+        if (!p.made) continue;
+        if (p.in_use) (void)hipEventSynchronize(p.done);
+        if (p.h_status) (void)hipHostFree(p.h_status);
+        if (p.done) (void)hipEventDestroy(p.done);
+        for (int i = 0; i < kEvCount; i++) if (p.ev[i]) (void)hipEventDestroy(p.ev[i]);
+    }
     if (c->have_pipe) {
         for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev_in[i]);
         for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_out[i]); c->p_out[i].release(); c->p_outoff[i].release(); }
@@ -515,6 +548,104 @@ int l3_encode_batch_device(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, c
     int rc = encode_core(c, A, s, n_tok, nullptr);
     if (rc == L3_E_OUTPUT_CAP) c->err = "output buffer too small";
     return rc;
+}
+
+// ---- stream-ordered calls ------------------------------------------------------------------------------------
+int l3_encode_submit(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+                     uint32_t flags, int32_t* d_out_tok, uint64_t out_cap, uint64_t* d_out_off, void* stream, int* ticket) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!ticket || !d_doc_off || !d_out_off || (!d_text && n_bytes) || (!d_out_tok && out_cap)) {
+        c->err = "null pointer argument";
+        return L3_E_INVALID_ARG;
+    }
+    *ticket = -1;
+    if (bad_flags(c, flags)) return L3_E_INVALID_ARG;
+    if (n_bytes >= (1ull << 40) || n_docs >= 0xFFFFFFFEull || num_tiles(n_bytes) > 0x7FFFFFFFull) {
+        c->err = "batch too large: split it (n_bytes < 2^40, n_docs < 2^32-2)";
+        return L3_E_INVALID_ARG;
+    }
+    int slot = -1;
+    for (int i = 0; i < L3_MAX_PENDING; i++)
+        if (!c->pend[i].in_use) { slot = i; break; }
+    if (slot < 0) { c->err = "L3_MAX_PENDING batches are pending already: l3_encode_wait for one first"; return L3_E_INVALID_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    l3_ctx::Pending& P = c->pend[slot];
+    if (!P.made) {
+        HIPCHK(c, hipHostMalloc((void**)&P.h_status, sizeof(Status), hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&P.done, hipEventDisableTiming));
+        for (int i = 0; i < kEvCount; i++) HIPCHK(c, hipEventCreate(&P.ev[i]));
+        P.made = true;
+    }
+    // the workspace is shared with the batches still in flight: it may only be moved (grown) once they are through
+    {
+        Workspace W0{};
+        Caps K = c->caps;
+        const Caps K0 = initial_caps(n_bytes);
+        if (K.slow_cap < K0.slow_cap) K.slow_cap = K0.slow_cap;
+        if (K.miss_shard_cap < K0.miss_shard_cap) K.miss_shard_cap = K0.miss_shard_cap;
+        if (K.pool_cap < K0.pool_cap) K.pool_cap = K0.pool_cap;
+        if (K.mpool_shard_cap < K0.mpool_shard_cap) K.mpool_shard_cap = K0.mpool_shard_cap;
+        if (K.scratch_cap < K0.scratch_cap) K.scratch_cap = K0.scratch_cap;
+        if (K.win_cap < K0.win_cap) K.win_cap = K0.win_cap;
+        if (carve_workspace(nullptr, n_bytes, n_docs, K, nullptr, W0) > c->w_arena.cap && c->n_pending) {
+            int rc0 = drain_pending(c);
+            if (rc0) return rc0;
+        }
+    }
+    Workspace W{};
+    int rc = ensure_workspace(c, n_bytes, n_docs, W);
+    if (rc) return rc;
+    EncodeArgs A{};
+    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = flags;
+    A.out_tok = d_out_tok; A.out_cap = out_cap; A.out_off = d_out_off; A.kinds = nullptr;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if ((rc = order_behind_last(c, s))) return rc;
+    if (c->status_dirty) { HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), s)); c->status_dirty = false; }
+    P.profiled = c->profiling;
+    HIPCHK(c, launch_encode(c->T, W, A, s, P.profiled ? P.ev : nullptr, false));
+    HIPCHK(c, launch_emit_generic(W, A, s));   // nobody reads the status word in between: the (rare) flagged tiles are looked for every time
+    HIPCHK(c, launch_status_out(W, P.h_status, s, 2));   // (a batch that needs a host-driven pass is run again by its wait)
+    if ((rc = mark_batch_end(c, s))) return rc;
+    HIPCHK(c, hipEventRecord(P.done, s));
+    P.A = A; P.stream = s; P.in_use = true;
+    c->n_pending++;
+    *ticket = slot;
+    return L3_OK;
+}
+
+int l3_encode_wait(l3_ctx* c, int ticket, uint64_t* n_tok) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!n_tok || ticket < 0 || ticket >= L3_MAX_PENDING || !c->pend[ticket].in_use) { c->err = "no such pending batch"; return L3_E_INVALID_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    l3_ctx::Pending& P = c->pend[ticket];
+    HIPCHK(c, hipEventSynchronize(P.done));
+    P.in_use = false;
+    c->n_pending--;
+    const Status st = *P.h_status;
+    if (st.flags & kBadOffsets) { c->err = "doc_off must start at 0, be ascending and end at n_bytes"; return L3_E_INVALID_ARG; }
+    if (st.flags & (kRetryFlags | kSeqPending | kGiantPending | kTooLong)) {
+        // the batch needs a larger workspace or the host-driven passes (long pre-tokens with invalid UTF-8, giant pieces):
+        // once more, synchronously (encode_core waits for the other pending batches first)
+        int rc = encode_core(c, P.A, P.stream, n_tok, nullptr);
+        if (rc == L3_E_OUTPUT_CAP) c->err = "output buffer too small";
+        return rc;
+    }
+    if (P.profiled) {
+        float ms[kEvCount];
+        for (int i = 0; i + 1 < kEvCount; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], P.ev[i], P.ev[i + 1]));
+        HIPCHK(c, hipEventElapsedTime(&ms[kEvCount - 1], P.ev[kEvStart], P.ev[kEvEmit]));
+        for (int i = 0; i < kEvCount; i++) { c->last_ms[i] = ms[i]; c->sum_ms[i] += ms[i]; }
+        c->sum_calls++;
+    }
+    uint64_t miss_total = 0, mpool_total = 0;
+    for (int i = 0; i < kMissShards; i++) { miss_total += st.shard[i].miss_count; mpool_total += st.shard[i].pool_used; }
+    c->counters[0] = num_tiles(P.A.n_bytes); c->counters[1] = st.slow_count; c->counters[2] = st.pool_used + mpool_total;
+    c->counters[3] = st.scratch_used; c->counters[4] = 0; c->counters[5] = miss_total; c->counters[6] = st.slow_q.count; c->counters[7] = 0;
+    *n_tok = st.total_tokens;
+    if (st.flags & kOvfOut) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
+    return L3_OK;
 }
 
 // list capacities of the allocation-free entry point: fixed, sized for its largest batch

@@ -198,6 +198,9 @@ enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvEmit, kEvC
 // the caller enlarged the output buffer).
 hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream,
                          hipEvent_t* ev, bool emit_only);
+// The status word to `host_dst` (page-locked host memory); clear: 0 = it is left as it is, 1 = zeroed unless kSeqPending or
+// kGiantPending is set (the host-driven passes still need it), 2 = zeroed.
+hipError_t launch_status_out(const Workspace& W, Status* host_dst, hipStream_t stream, int clear = 1);
 // Second pass of slow_kernel (clears kSeqPending first): the windows of the long pre-tokens with invalid UTF-8 that the
 // first pass expanded.
 hipError_t launch_slow_second_pass(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream);

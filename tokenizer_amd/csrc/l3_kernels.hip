@@ -2895,6 +2895,25 @@ static hipError_t launch_totals_scan(const Workspace& W, const EncodeArgs& A, hi
 
 __global__ void status_and_kernel(Status* st, uint32_t mask) { st->flags &= mask; }
 
+// The status word to the host (page-locked, device-visible memory) and, unless a host-driven pass is still to come,
+// back to zero for the next batch: one small kernel instead of a copy and a memset between two batches.
+// clear: 0 = leave it, 1 = zero it unless kSeqPending / kGiantPending is set, 2 = zero it.
+__global__ __launch_bounds__(256) void status_out_kernel(Status* st, Status* host_dst, int clear) {
+    uint32_t* src = reinterpret_cast<uint32_t*>(st);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(host_dst);
+    const uint32_t fl = st->flags;
+    constexpr uint32_t n_words = sizeof(Status) / 4;
+    for (uint32_t i = threadIdx.x; i < n_words; i += 256) dst[i] = src[i];
+    __syncthreads();
+    if (clear == 0 || (clear == 1 && (fl & (kSeqPending | kGiantPending)))) return;
+    for (uint32_t i = threadIdx.x; i < n_words; i += 256) src[i] = 0;
+}
+hipError_t launch_status_out(const Workspace& W, Status* host_dst, hipStream_t stream, int clear) {
+    hipLaunchKernelGGL(status_out_kernel, dim3(1), dim3(256), 0, stream, W.status, host_dst, clear);
+    L3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_slow_second_pass(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
     hipLaunchKernelGGL(status_and_kernel, dim3(1), dim3(1), 0, stream, W.status, ~(uint32_t)kSeqPending);
     L3_LAUNCH_CHECK();
