@@ -220,20 +220,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx.set_profiling(True)   # HIP events on the launch stream around every kernel of every call
+    # Timed region: HIP events on the launch stream only where the roofline figures need them (before and behind the tile
+    # kernel, first kernel start, last kernel end).  An event between two kernels keeps the second from starting early;
+    # the full per-kernel breakdown therefore comes from a second, UNTIMED pass over the same batches below.
+    ctx.set_profiling(2)
     run(0, len(warm_batches))
     sync()
-    ctx.set_profiling(True)   # resets the library's per-kernel sums: they cover exactly the timed steps
+    ctx.set_profiling(2)      # resets the library's sums: they cover exactly the timed steps
     t0 = time.perf_counter()
     n_tok_total = run(0, steps)
     sync()
     dt = time.perf_counter() - t0
-    kern, n_prof = ctx.timing_totals()
-    ctx.set_profiling(False)
+    kern_timed, n_prof = ctx.timing_totals()
     if n_prof != steps:
         raise RuntimeError("profiled %d calls, expected %d (a call was retried with a larger workspace?)" % (n_prof, steps))
+    ctx.set_profiling(1)      # untimed: events between all kernels
+    run(0, steps)
+    sync()
+    kern, n_prof2 = ctx.timing_totals()
+    ctx.set_profiling(False)
     for k in kern:
-        kern[k] /= max(steps, 1)
+        kern[k] /= max(n_prof2, 1)
+        kern_timed[k] /= max(steps, 1)
     counters = ctx.last_counters()
     last_tok = int(n_out.value)
 
@@ -256,9 +264,11 @@ def main():
         value = tot_tok / dt
         tok_per_batch = n_tok_total / steps
         ba = b_alg(n_bytes, tok_per_batch, n_docs)
-        dom = max(("tile", "merge", "slow", "emit", "scan", "docs"), key=lambda k: kern[k])
-        pipeline = ba / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
-        dom_gbs = ba / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        dom = max(("tile", "merge", "slow", "emit", "scan", "docs"), key=lambda k: kern[k])   # (from the untimed breakdown)
+        t_kernels = kern_timed["total"]                                  # first kernel start -> last kernel end, timed steps
+        t_dom = kern_timed[dom] if dom in ("tile", "docs") else kern[dom]  # the timed region brackets the tile kernel only
+        pipeline = ba / (t_kernels * 1e-3) / 1e9 if t_kernels > 0 else 0.0
+        dom_gbs = ba / (t_dom * 1e-3) / 1e9 if t_dom > 0 else 0.0
         if args.config == "c5":
             workload = ("C5: %d synthetic English docs x %d B (%.1f GiB) generated on the owning GPU, sharded by document over %d "
                         "GPU(s), %d batches of %d docs per GPU encoded back to back, BOS+EOS, inputs and outputs resident in HBM"
@@ -278,12 +288,15 @@ def main():
             "tokens_total": tot_tok, "tokens_per_batch": tok_per_batch,
             "bytes_per_token": my_bytes / max(n_tok_total - 2 * my_docs, 1),
             "corpus_generation_s": gen_s,
-            "kernel_ms": kern, "deferred_pretokens_last_batch": {"short": counters["short_pretokens"], "slow": counters["slow_pretokens"]},
+            "kernel_ms": kern, "kernel_ms_note": "per-kernel breakdown from an untimed pass over the same batches with events between all kernels",
+            "kernel_ms_timed": {"docs": kern_timed["docs"], "tile": kern_timed["tile"], "total": kern_timed["total"]},
+            "deferred_pretokens_last_batch": {"short": counters["short_pretokens"], "slow": counters["slow_pretokens"]},
             # frac: algorithmic bytes / (first kernel start -> last kernel end) / peak, as SURVEY 8(d) defines it
             "roofline": {"bound": "hbm", "achieved": pipeline, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pipeline / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": ba, "kernels_ms_per_launch": kern["total"],
+                         "traffic": None, "algorithmic_bytes_per_launch": ba, "kernels_ms_per_launch": t_kernels,
                          "wall_frac": ba / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "dominant": {"kernel": dom + "_kernel", "avg_ms": kern[dom], "achieved": dom_gbs, "frac": dom_gbs / HBM_PEAK_GBS}},
+                         "dominant": {"kernel": dom + "_kernel", "avg_ms": t_dom, "achieved": dom_gbs, "frac": dom_gbs / HBM_PEAK_GBS,
+                                      "measured_in": "timed steps" if dom in ("tile", "docs") else "untimed breakdown pass"}},
         }
         # HBM traffic per launch (all kernels of the pipeline) from the committed rocprofv3 PMC passes of this command --
         # quoted only when that summary was taken from exactly these kernel sources

@@ -243,6 +243,7 @@ class Context:
         return None if n < 0 else buf[:n].tobytes()
 
     def set_profiling(self, on=True):
+        """True / 1: events between all kernels; 2: only around the tile kernel and first start / last end; False: none"""
         self.lib.l3_set_profiling(self.h, int(on))
 
     def last_timings(self):

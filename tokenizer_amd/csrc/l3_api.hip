@@ -96,14 +96,14 @@ struct l3_ctx {
     hipEvent_t ev_in[8] = {}, ev_out[2] = {};
     bool have_pipe = false;
     hipEvent_t ev[kEvCount] = {};
-    bool have_events = false, profiling = false;
+    bool have_events = false, profiling = false, profiling_light = false;
     float last_ms[kEvCount] = {};
     double sum_ms[kEvCount] = {};     // over the profiled calls since profiling was switched on
     uint64_t sum_calls = 0;
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // stream-ordered calls (l3_encode_submit / l3_encode_wait): what each pending batch left for its wait
     struct Pending {
-        bool in_use = false, made = false, profiled = false;
+        bool in_use = false, made = false, profiled = false, light = false;
         EncodeArgs A{};
         hipStream_t stream = nullptr;
         Status* h_status = nullptr;   // pinned
@@ -279,6 +279,20 @@ int rerun_emit(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t s
     return mark_batch_end(c, stream);
 }
 
+// Milliseconds between the events of one profiled call: [docs, tile, merge, slow, scan, emit, first start -> last end]; in
+// light mode only docs, tile and the total exist (the others are 0).
+int event_times(l3_ctx* c, hipEvent_t* ev, bool light, float* ms) {
+    for (int i = 0; i < kEvCount; i++) ms[i] = 0;
+    if (light) {
+        HIPCHK(c, hipEventElapsedTime(&ms[0], ev[kEvStart], ev[kEvDocs]));
+        HIPCHK(c, hipEventElapsedTime(&ms[1], ev[kEvDocs], ev[kEvTile]));
+    } else {
+        for (int i = 0; i + 1 < kEvCount; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    }
+    HIPCHK(c, hipEventElapsedTime(&ms[kEvCount - 1], ev[kEvStart], ev[kEvEmit]));
+    return L3_OK;
+}
+
 // Waits for the batches queued by l3_encode_submit (they share the workspace with every other call on the context).
 int drain_pending(l3_ctx* c) {
     for (auto& p : c->pend)
@@ -337,7 +351,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         // clear runs while the host is busy between two calls instead of in front of the kernels
         if ((rc = order_behind_last(c, stream))) return rc;
         if (c->status_dirty) { HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream)); c->status_dirty = false; }
-        HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false));
+        HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false, c->profiling_light ? kEvLight : kEvAll));
         HIPCHK(c, launch_status_out(W, c->h_status, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
         if (c->h_status->flags & (kSeqPending | kGiantPending)) c->status_dirty = true;   // until a pass below has handed it out cleared
@@ -401,14 +415,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
             continue;
         }
         if (c->profiling) {
-            float total = 0;
-            for (int i = 0; i + 1 < kEvCount; i++) {
-                float ms = 0;
-                HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-                c->last_ms[i] = ms;
-            }
-            HIPCHK(c, hipEventElapsedTime(&total, c->ev[kEvStart], c->ev[kEvEmit]));
-            c->last_ms[kEvCount - 1] = total;
+            if ((rc = event_times(c, c->ev, c->profiling_light, c->last_ms))) return rc;
             for (int i = 0; i < kEvCount; i++) c->sum_ms[i] += c->last_ms[i];
             c->sum_calls++;
         }
@@ -603,7 +610,8 @@ int l3_encode_submit(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, const u
     if ((rc = order_behind_last(c, s))) return rc;
     if (c->status_dirty) { HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), s)); c->status_dirty = false; }
     P.profiled = c->profiling;
-    HIPCHK(c, launch_encode(c->T, W, A, s, P.profiled ? P.ev : nullptr, false));
+    P.light = c->profiling_light;
+    HIPCHK(c, launch_encode(c->T, W, A, s, P.profiled ? P.ev : nullptr, false, P.light ? kEvLight : kEvAll));
     HIPCHK(c, launch_emit_generic(W, A, s));   // nobody reads the status word in between: the (rare) flagged tiles are looked for every time
     HIPCHK(c, launch_status_out(W, P.h_status, s, 2));   // (a batch that needs a host-driven pass is run again by its wait)
     if ((rc = mark_batch_end(c, s))) return rc;
@@ -634,8 +642,8 @@ int l3_encode_wait(l3_ctx* c, int ticket, uint64_t* n_tok) {
     }
     if (P.profiled) {
         float ms[kEvCount];
-        for (int i = 0; i + 1 < kEvCount; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], P.ev[i], P.ev[i + 1]));
-        HIPCHK(c, hipEventElapsedTime(&ms[kEvCount - 1], P.ev[kEvStart], P.ev[kEvEmit]));
+        int rc = event_times(c, P.ev, P.light, ms);
+        if (rc) return rc;
         for (int i = 0; i < kEvCount; i++) { c->last_ms[i] = ms[i]; c->sum_ms[i] += ms[i]; }
         c->sum_calls++;
     }
@@ -980,6 +988,7 @@ int l3_set_profiling(l3_ctx* c, int enabled) {
     if (!c) return L3_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     c->profiling = enabled != 0;
+    c->profiling_light = enabled == 2;
     for (int i = 0; i < kEvCount; i++) c->sum_ms[i] = 0;
     c->sum_calls = 0;
     return L3_OK;

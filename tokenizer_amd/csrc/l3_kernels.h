@@ -196,8 +196,10 @@ enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvEmit, kEvC
 // Enqueue the encode pipeline on `stream`; nothing is synchronised.  `ev` (optional, kEvCount
 // events) are recorded between the kernels.  `emit_only` re-runs just the final scatter (after
 // the caller enlarged the output buffer).
+// `ev_mask`: which of the events are recorded (bit i = event i); kEvLight = only what the roofline figures need.
+constexpr uint32_t kEvAll = 0xFFFFFFFFu, kEvLight = (1u << kEvStart) | (1u << kEvDocs) | (1u << kEvTile) | (1u << kEvEmit);
 hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream,
-                         hipEvent_t* ev, bool emit_only);
+                         hipEvent_t* ev, bool emit_only, uint32_t ev_mask = kEvAll);
 // The status word to `host_dst` (page-locked host memory); clear: 0 = it is left as it is, 1 = zeroed unless kSeqPending or
 // kGiantPending is set (the host-driven passes still need it), 2 = zeroed.
 hipError_t launch_status_out(const Workspace& W, Status* host_dst, hipStream_t stream, int clear = 1);

@@ -2862,7 +2862,7 @@ __global__ __launch_bounds__(256) void decode_copy_kernel(const uint32_t* tok_of
     } while (0)
 #define L3_EV(i)                                                          \
     do {                                                                  \
-        if (ev) {                                                         \
+        if (ev && ((ev_mask >> (i)) & 1u)) {                              \
             hipError_t e_ = hipEventRecord(ev[i], stream);                \
             if (e_ != hipSuccess) return e_;                              \
         }                                                                 \
@@ -2933,7 +2933,7 @@ hipError_t launch_encode_tail(const Workspace& W, const EncodeArgs& A, hipStream
 }
 
 hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream, hipEvent_t* ev,
-                         bool emit_only) {
+                         bool emit_only, uint32_t ev_mask) {
     const uint64_t n_tiles = num_tiles(A.n_bytes);
     if (n_tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (!emit_only) {
