@@ -78,6 +78,8 @@ struct l3_ctx {
     // The status word is zero between two calls: the kernel that hands it to the host (status_out_kernel) clears it, in
     // stream order behind the batch.  Calls on DIFFERENT streams are ordered by an event the context owns, recorded behind
     // every batch: the caller's stream handle is never kept, it may be destroyed between two calls.
+    uint32_t slow_grid = 32;          // slow_kernel's grid for the next batch: all of it once a batch had window items, a few
+                                      // workgroups (an empty launch costs 8 us otherwise) while batches have none
     bool status_dirty = false;        // a call ended (with an error) between two host-driven passes: the word is zeroed first
     bool order_pending = false;       // ev_order has been recorded behind the last batch
     bool order_on_own = false;        // ... on the context's own stream (same-stream order makes the wait unnecessary)
@@ -250,6 +252,7 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     carve_workspace(c->w_arena.as<uint8_t>(), n_bytes, n_docs, K, c->w_status.as<Status>(), W);
     W.bos_id = c->H.special_id[0];  // canonical index 0 / 1 = <|begin_of_text|> / <|end_of_text|> (l3_tables.cpp)
     W.eos_id = c->H.special_id[1];
+    W.slow_grid = c->slow_grid;
     return L3_OK;
 }
 
@@ -425,6 +428,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         c->counters[3] = st.scratch_used;
         c->counters[5] = miss_total;
         c->counters[6] = st.slow_q.count;
+        c->slow_grid = st.slow_count > 64 ? 0u : 32u;   // (the slow list feeds the wave pass and slow_kernel)
         *n_tok = st.total_tokens;
         if (W_out) *W_out = W;
         return (st.flags & kOvfOut) ? L3_E_OUTPUT_CAP : L3_OK;
@@ -651,6 +655,7 @@ int l3_encode_wait(l3_ctx* c, int ticket, uint64_t* n_tok) {
     for (int i = 0; i < kMissShards; i++) { miss_total += st.shard[i].miss_count; mpool_total += st.shard[i].pool_used; }
     c->counters[0] = num_tiles(P.A.n_bytes); c->counters[1] = st.slow_count; c->counters[2] = st.pool_used + mpool_total;
     c->counters[3] = st.scratch_used; c->counters[4] = 0; c->counters[5] = miss_total; c->counters[6] = st.slow_q.count; c->counters[7] = 0;
+    c->slow_grid = st.slow_count > 64 ? 0u : 32u;   // (the slow list feeds the wave pass and slow_kernel)
     *n_tok = st.total_tokens;
     if (st.flags & kOvfOut) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
     return L3_OK;

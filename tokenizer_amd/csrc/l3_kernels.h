@@ -15,8 +15,6 @@ constexpr int kTile = L3_TILE_BYTES;  // bytes of text owned by one workgroup
 constexpr int kBack = 64;         // look-behind halo (special token 30 B + 4 runes 16 B + slack)
 constexpr int kFwd = 192;         // look-ahead halo
 constexpr int kRegion = kBack + kTile + kFwd;  // 4096: one 64-bit mask word per lane of a wave, 16 bytes per thread
-constexpr int kSBack = 64;        // the slow kernel's end-finding window (its own LDS image, info word per byte)
-constexpr int kSRegion = 2304;
 constexpr int kEvalSlack = 36;    // positions closer than this to a soft region end cannot be decided
 constexpr int kLaneMax = 64;      // longest pre-token (bytes) merged by a single lane in the tile kernel
 constexpr int kTileCap = kTile;  // stream items one tile can emit: one per pre-token that starts in it
@@ -166,6 +164,7 @@ struct Workspace {
     int32_t* pool;          // [kMissShards * mpool_shard_cap + pool_cap]: results of more than kMissInline tokens of the
                             // merge kernel, one part per shard, then the tokens of the slow pre-tokens
     uint8_t* scratch;       // [scratch_cap] symbol arrays of pre-tokens too long for LDS
+    uint32_t slow_grid;     // workgroups of slow_kernel (0: the default); the host keeps it small while batches have no long pre-tokens
     uint32_t allow_giants;  // 0: no piece is left to the grid-wide merge (the allocation-free entry point: that path allocates)
     Giant* giants;          // [kMaxGiants]
     GiantState* gstate;

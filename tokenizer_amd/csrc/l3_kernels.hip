@@ -29,11 +29,6 @@ namespace l3 {
 
 namespace {
 
-constexpr int kPer = kSRegion / kTileThreads;  // consecutive region positions owned by one thread
-static_assert(kPer * kTileThreads == kSRegion, "region must split evenly over the workgroup");
-static_assert(kPer <= 32, "per-thread masks are 32 bit");
-constexpr int kBitWords = kSRegion / 32 + 2;
-
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
@@ -86,48 +81,6 @@ __device__ __forceinline__ Seg seg_comb(Seg a, Seg b) {
     r.open = a.open & b.open;
     return r;
 }
-__device__ __forceinline__ Seg block_seg_escan(Seg v, Seg* tmp) {
-    Seg inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        Seg t;
-        t.cnt = __shfl_up(inc.cnt, d, 64);
-        t.open = __shfl_up(inc.open, d, 64);
-        if (lane_id() >= d) inc = seg_comb(t, inc);
-    }
-    Seg ex;
-    ex.cnt = __shfl_up(inc.cnt, 1, 64);
-    ex.open = __shfl_up(inc.open, 1, 64);
-    if (lane_id() == 0) { ex.cnt = 0; ex.open = 1; }
-    if (lane_id() == 63) tmp[wave_id()] = inc;
-    __syncthreads();
-    Seg base; base.cnt = 0; base.open = 1;
-    for (int i = 0; i < wave_id(); i++) base = seg_comb(base, tmp[i]);
-    __syncthreads();
-    return seg_comb(base, ex);
-}
-
-// ---- the LDS image of one region of text --------------------------------------------------------
-struct RegionLds {
-    uint8_t b[kSRegion + 16];     // raw bytes (16-byte aligned for vector stores)
-    uint32_t a[kSRegion + 8];     // info word per byte; later: token id / kDead / kSlowMark / kMissMark
-    uint32_t p[kSRegion + 8];     // special-token id; later: pair priority / deferred length
-    uint32_t dsb[kBitWords];     // document-start bits
-    uint32_t stb[kBitWords];     // pre-token-start bits
-};
-enum { V_NPRE = 0, V_FIRST, V_ELAST, V_NEED, V_FB, V_SLOW0, V_NMISS, V_END, V_COUNT = 16 };
-
-// byte source + info source over the region, in LOCAL coordinates [0, n)
-struct LdsSrc {
-    const RegionLds* R;
-    int n;
-    bool hard;  // position n is the end of the text / document (a hard barrier)
-    __device__ uint32_t b(int64_t q) const { return R->b[q]; }
-    __device__ bool ds(int64_t q) const { return (q == n && hard) || ((R->dsb[q >> 5] >> (q & 31)) & 1u); }
-    __device__ int64_t lo() const { return 0; }
-    __device__ int64_t hi() const { return n; }
-    __device__ uint32_t info(int64_t q) const { return R->a[q]; }
-};
 // byte source over global memory restricted to one segment [lo, hi)
 struct GlobalSrc {
     const uint8_t* t;
@@ -137,66 +90,6 @@ struct GlobalSrc {
     __device__ int64_t lo() const { return lo_; }
     __device__ int64_t hi() const { return hi_; }
 };
-
-__device__ __forceinline__ void region_load(RegionLds& R, const uint8_t* text, uint64_t g_lo, int n) {
-    const uint8_t* src = text + g_lo;
-    const bool aligned = (((uintptr_t)src) & 15u) == 0;
-    for (int g = threadIdx.x; g * 16 < n + 16; g += blockDim.x) {
-        int o = g * 16;
-        if (aligned && o + 16 <= n) {
-            *reinterpret_cast<uint4*>(&R.b[o]) = *reinterpret_cast<const uint4*>(src + o);
-        } else {
-            for (int k = 0; k < 16; k++)
-                if (o + k < kSRegion + 16) R.b[o + k] = (o + k < n) ? src[o + k] : (uint8_t)0;
-        }
-    }
-}
-
-// info words (class, rune start, validity) + special-token overlay.  dsb must be final; contains barriers.
-__device__ __forceinline__ void region_classify(RegionLds& R, const LdsSrc& src, const Tables& T, bool specials) {
-    const int c0 = threadIdx.x * kPer;
-    const int n = src.n;
-#pragma unroll 1
-    for (int j = 0; j < kPer; j++) {
-        int q = c0 + j;
-        if (q < n) R.a[q] = byte_info(src, q, T.cls_stage1, T.cls_blocks);
-        else if (q < kSRegion + 8) R.a[q] = I_SEG | I_RUNE;
-    }
-    if (threadIdx.x < 8) R.a[kSRegion + threadIdx.x] = I_SEG | I_RUNE;
-    __syncthreads();
-#pragma unroll 1
-    for (int j = 0; j < kPer; j++) {
-        int q = c0 + j;
-        if (!specials || q >= n || R.b[q] != '<') continue;
-        int canon = 0;
-        int len = special_match(src, q, &canon);
-        if (!len) continue;
-        int32_t id = T.special_id[canon];
-        atomicOr(&R.a[q], I_SEG);
-        atomicOr(&R.a[q + len], I_SEG);
-        if (id != 0) {  // tokenizer.go:236: only a piece whose lookup is non-zero is emitted as special
-            atomicOr(&R.a[q], I_SPECIAL);
-            R.p[q] = (uint32_t)id;
-            for (int k = 1; k < len; k++) R.a[q + k] = I_SPBODY;
-        }
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ int find_next_bit(const uint32_t* bits, int from, int limit) {
-    if (from >= limit) return -1;
-    int w = from >> 5;
-    uint32_t x = bits[w] & (0xFFFFFFFFu << (from & 31));
-    const int wl = (limit - 1) >> 5;
-    for (;;) {
-        if (x) {
-            int q = (w << 5) + __builtin_ctz(x);
-            return q < limit ? q : -1;
-        }
-        if (++w > wl) return -1;
-        x = bits[w];
-    }
-}
 
 // number of consecutive Nd runes immediately before global position `pos` (= the start of tile `tile`) inside
 // [seg_lo, seg_hi)  (whole workgroup; pathological digit runs longer than the look-behind halo only).
@@ -2918,6 +2811,7 @@ hipError_t launch_slow_second_pass(const Tables& T, const Workspace& W, const En
     hipLaunchKernelGGL(status_and_kernel, dim3(1), dim3(1), 0, stream, W.status, ~(uint32_t)kSeqPending);
     L3_LAUNCH_CHECK();
     uint64_t sgrid = W.slow_cap < L3_SLOW_GRID ? W.slow_cap : L3_SLOW_GRID;
+    if (W.slow_grid && W.slow_grid < sgrid) sgrid = W.slow_grid;
     if (sgrid == 0) sgrid = 1;
     hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A, 1);
     L3_LAUNCH_CHECK();
@@ -2951,6 +2845,7 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
 #define L3_SLOW_GRID 512
 #endif
         uint64_t sgrid = W.slow_cap < L3_SLOW_GRID ? W.slow_cap : L3_SLOW_GRID;
+        if (W.slow_grid && W.slow_grid < sgrid) sgrid = W.slow_grid;
         if (sgrid == 0) sgrid = 1;
         {
             uint64_t mgrid = ((W.miss_shard_cap + kMergeThreads - 1) / kMergeThreads) * kMissShards;  // windows at most

@@ -6,9 +6,12 @@ random 16-byte probes (merge_kernel) the factor is uncalibrated and the figure i
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def collect(d, counter):
@@ -26,7 +29,9 @@ def collect(d, counter):
 
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+import bench  # noqa: E402  (source_digest: bench.py quotes a summary only if it was taken from the same kernel sources)
+
+out = {"source_digest": bench.source_digest(), "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs (tools/profile_round.sh)",
        "note": "gfx950: FETCH_SIZE counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md), so bytes = "
                "2*FETCH_SIZE + WRITE_SIZE; counter unit KB", "kernels": {}}
 for k in fetch:

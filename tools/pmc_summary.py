@@ -23,3 +23,8 @@ for k in sorted(meta):
     print("%-22s vgpr=%s agpr=%s sgpr=%s lds=%s scratch=%s grid=%s wg=%s" % ((k,) + meta[k]))
 for (k, c), (s, n) in sorted(acc.items()):
     print("%-22s %-24s %.4e  (n=%d)" % (k, c, s / n, n))
+# LDS bank conflicts as a share of the cycles the LDS was busy (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
+for k in sorted(meta):
+    c, a = acc.get((k, "SQ_LDS_BANK_CONFLICT")), acc.get((k, "SQ_LDS_IDX_ACTIVE"))
+    if c and a and a[0] > 0:
+        print("%-22s LDS conflict cycles / LDS active cycles = %.3f" % (k, (c[0] / c[1]) / (a[0] / a[1])))
