@@ -40,6 +40,13 @@ typedef struct l3_ctx l3_ctx;
  * are appended as the reference does.  On failure *out is NULL and l3_last_error(NULL) has the reason. */
 int l3_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len, int device,
               l3_ctx** out);
+/* llama3.New(llama3.WithSpecialTokens(list)) (options.go:17-37, tokenizer.go:194-198): the list REPLACES the 256 defaults;
+ * its tokens get the ids behind the vocabulary in list order.  As in the reference the text is still split at the 256
+ * DEFAULT names (tokenizer.go:27,232), and a name that is not in the list is ordinary text (tokenizer.go:236); BOS / EOS
+ * are added only if the list holds <|begin_of_text|> / <|end_of_text|> (tokenizer.go:225-229,258-262).  special_tokens ==
+ * NULL: the defaults (l3_create).  A malformed or repeated entry: L3_E_INVALID_ARG (reference: *ConfigError). */
+int l3_create_ex(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len,
+                 const char* const* special_tokens, size_t n_special, int device, l3_ctx** out);
 void l3_destroy(l3_ctx* ctx);
 /* text of the last error on this context (ctx == NULL: of the last failed l3_create on this thread) */
 const char* l3_last_error(const l3_ctx* ctx);

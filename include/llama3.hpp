@@ -14,6 +14,9 @@
 //   scanner::Tokenizer, scanner::New/NewWithOptions, Scanner::Scan/Token/Text/Err
 //                                             llama3/scanner/scanner.go:12-111,241-333 (chunking rules :124-181,337-478)
 //   Tokenizer::NewScanner / Process           llama3/scanner.go:67-102 (Process writes uint32 little-endian)
+//   Tokenizer::TokenStream                    llama3/scanner.go:107-132 (a bounded channel of 100 fed by a thread)
+//   WithSpecialTokens                         options.go:17-37 (the list replaces the 256 defaults; ConfigError on a
+//                                             malformed or duplicated name)
 //   EncodeStreams                             new, additive: many streams, the scanner's chunks, ONE batch call
 #pragma once
 #include <stdint.h>
@@ -21,9 +24,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "l3hip.h"
@@ -31,7 +38,7 @@
 namespace llama3 {
 
 // ---- errors (llama3/errors.go) ------------------------------------------------------------------------
-enum class ErrKind { None, DataNotFound, InvalidToken, TokenNotFound, Device, Reader };
+enum class ErrKind { None, DataNotFound, InvalidToken, TokenNotFound, Device, Reader, Config };
 struct Error {
     ErrKind kind = ErrKind::None;
     std::string op, detail;
@@ -48,21 +55,43 @@ struct EncodeOptions {  // tokenizer.go:107-112
 struct Config {
     std::string vocabPath, mergesPath;  // WithDataFiles
     int device = 0;                     // new: which GPU holds the tables
+    bool haveSpecials = false;          // WithSpecialTokens with a non-nil list (an empty one counts: no special tokens)
+    std::vector<std::string> specialTokens;
+    Error err;                          // the first option that failed (New returns it, tokenizer.go:151-155)
 };
 typedef void (*OptionFn)(Config&, const void*);
 struct Option {
     std::string a, b;
     int i = 0;
     int which = 0;
+    std::vector<std::string> list;
     void Apply(Config& c) const {
         if (which == 1) { c.vocabPath = a; c.mergesPath = b; }
         if (which == 2) c.device = i;
+        if (which == 3) {  // options.go:19-33: each name is <|...|> of at least 5 bytes, and none appears twice
+            for (size_t k = 0; k < list.size(); k++) {
+                const std::string& t = list[k];
+                const bool shaped = t.size() >= 5 && t.compare(0, 2, "<|") == 0 && t.compare(t.size() - 2, 2, "|>") == 0;
+                bool dup = false;
+                for (size_t j = k + 1; j < list.size() && !dup; j++) dup = list[j] == t;
+                if ((!shaped || dup) && !c.err) {
+                    c.err.kind = ErrKind::Config;
+                    c.err.op = "special_tokens";
+                    c.err.detail = std::string(shaped ? "duplicate: " : "validate: ") + t;
+                    return;
+                }
+            }
+            c.haveSpecials = true;
+            c.specialTokens = list;
+        }
     }
 };
 inline Option WithDataFiles(const std::string& vocabPath, const std::string& mergesPath) {
     Option o; o.which = 1; o.a = vocabPath; o.b = mergesPath; return o;
 }
 inline Option WithDevice(int device) { Option o; o.which = 2; o.i = device; return o; }
+// options.go:17-37.  Go's nil slice (keep the defaults) is "do not pass the option" here.
+inline Option WithSpecialTokens(const std::vector<std::string>& tokens) { Option o; o.which = 3; o.list = tokens; return o; }
 
 // ---- io: the two interfaces the streaming surface needs (Go's io.Reader / io.Writer) -------------------
 struct Reader {
@@ -286,6 +315,60 @@ class Scanner {
 
 }  // namespace scanner
 
+// llama3/scanner.go:107-132 -- the pair of channels TokenStream returns, as one object: a bounded queue of 100
+// tokens filled by a thread that runs the scanner; Next() is `tok, ok := <-tokens`, Err() is `<-errc` after the
+// token channel has closed.  The destructor drains and joins, so dropping a stream early is safe.
+class TokenChannel {
+  public:
+    TokenChannel(scanner::Tokenizer* t, Reader* r) : th_([this, t, r] { run(t, r); }) {}
+    ~TokenChannel() {
+        { std::lock_guard<std::mutex> lk(mu_); abandoned_ = true; }
+        not_full_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    TokenChannel(const TokenChannel&) = delete;
+    TokenChannel& operator=(const TokenChannel&) = delete;
+    // Blocks until a token is there (true) or the channel is closed and empty (false).
+    bool Next(int* tok) {
+        std::unique_lock<std::mutex> lk(mu_);
+        not_empty_.wait(lk, [this] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        *tok = q_.front();
+        q_.pop_front();
+        lk.unlock();
+        not_full_.notify_one();
+        return true;
+    }
+    // The scanner's error, once Next() has returned false (an empty Error when there was none).
+    Error Err() {
+        std::unique_lock<std::mutex> lk(mu_);
+        not_empty_.wait(lk, [this] { return closed_; });
+        return err_;
+    }
+    static constexpr size_t kCapacity = 100;  // make(chan int, 100)
+
+  private:
+    void run(scanner::Tokenizer* t, Reader* r) {
+        scanner::Scanner sc(t, r);
+        while (sc.Scan()) {
+            std::unique_lock<std::mutex> lk(mu_);
+            not_full_.wait(lk, [this] { return q_.size() < kCapacity || abandoned_; });  // a full channel blocks the sender
+            if (abandoned_) break;
+            q_.push_back(sc.Token());
+            lk.unlock();
+            not_empty_.notify_one();
+        }
+        { std::lock_guard<std::mutex> lk(mu_); err_ = sc.Err(); closed_ = true; }
+        not_empty_.notify_all();
+    }
+    std::mutex mu_;
+    std::condition_variable not_empty_, not_full_;
+    std::deque<int> q_;
+    bool closed_ = false, abandoned_ = false;
+    Error err_;
+    std::thread th_;  // last member: starts after everything it uses exists
+};
+
 // ---- the tokenizer ------------------------------------------------------------------------------------
 class Tokenizer : public scanner::Tokenizer {
   public:
@@ -344,7 +427,7 @@ class Tokenizer : public scanner::Tokenizer {
         int rc = l3_special_token_id(ctx_, token.data(), token.size(), &id);
         if (rc != L3_OK) {
             if (err) {
-                const bool shaped = token.size() >= 4 && token.compare(0, 2, "<|") == 0 && token.compare(token.size() - 2, 2, "|>") == 0;
+                const bool shaped = token.size() >= 2 && token.compare(0, 2, "<|") == 0 && token.compare(token.size() - 2, 2, "|>") == 0;
                 err->kind = shaped ? ErrKind::TokenNotFound : ErrKind::InvalidToken;
                 err->op = "get special token";
                 err->detail = token;
@@ -460,6 +543,8 @@ class Tokenizer : public scanner::Tokenizer {
         }
         return sc.Err() ? -1 : count;
     }
+    // TokenStream (llama3/scanner.go:107-132): tokens of r through a bounded channel, produced concurrently
+    std::unique_ptr<TokenChannel> TokenStream(Reader* r) { return std::unique_ptr<TokenChannel>(new TokenChannel(this, r)); }
     Error LastError() const { return last_; }
     l3_ctx* Handle() const { return ctx_; }
 
@@ -495,7 +580,10 @@ inline bool ReadFile(const std::string& path, std::string* out) {
 // WithDataFiles (options.go) or the L3_DATA_DIR environment variable.
 inline std::unique_ptr<Tokenizer> New(const std::vector<Option>& opts, Error* err) {
     Config c;
-    for (const Option& o : opts) o.Apply(c);
+    for (const Option& o : opts) {
+        o.Apply(c);
+        if (c.err) { if (err) *err = c.err; return nullptr; }  // tokenizer.go:151-155
+    }
     if (c.vocabPath.empty()) {
         const char* d = getenv("L3_DATA_DIR");
         std::string dir = d ? d : "tokenizer_amd/data";
@@ -508,7 +596,16 @@ inline std::unique_ptr<Tokenizer> New(const std::vector<Option>& opts, Error* er
         return nullptr;
     }
     std::unique_ptr<Tokenizer> t(new Tokenizer());
-    int rc = l3_create(vocab.data(), vocab.size(), merges.data(), merges.size(), c.device, &t->ctx_);
+    int rc;
+    if (c.haveSpecials) {
+        std::vector<const char*> names;
+        for (const std::string& n : c.specialTokens) names.push_back(n.c_str());
+        static const char* const none[1] = {nullptr};
+        rc = l3_create_ex(vocab.data(), vocab.size(), merges.data(), merges.size(), names.empty() ? none : names.data(), names.size(),
+                          c.device, &t->ctx_);
+    } else {
+        rc = l3_create(vocab.data(), vocab.size(), merges.data(), merges.size(), c.device, &t->ctx_);
+    }
     if (rc != L3_OK) {
         if (err) { err->kind = rc == L3_E_DATA ? ErrKind::DataNotFound : ErrKind::Device; err->op = "l3_create"; err->detail = l3_last_error(nullptr); }
         return nullptr;
@@ -546,13 +643,13 @@ inline Error EncodeStreams(Tokenizer& t, const std::vector<Reader*>& readers, co
     e = t.EncodeBatch((const uint8_t*)text.data(), off, &none, &ids, &id_off);
     if (e) return e;
     out->assign(readers.size(), std::vector<int>());
-    Error ig;
-    const int bos = t.GetSpecialTokenID("<|begin_of_text|>", &ig), eos = t.GetSpecialTokenID("<|end_of_text|>", &ig);
+    Error no_bos, no_eos;  // a custom special-token list may lack either: then none is added (scanner.go:188,195,232)
+    const int bos = t.GetSpecialTokenID("<|begin_of_text|>", &no_bos), eos = t.GetSpecialTokenID("<|end_of_text|>", &no_eos);
     for (size_t s = 0; s < readers.size(); s++) {
         std::vector<int>& v = (*out)[s];
-        if (o.enc.BOS && (first_chunk[s + 1] > first_chunk[s] || at_eof[s])) v.push_back(bos);
+        if (o.enc.BOS && !no_bos && (first_chunk[s + 1] > first_chunk[s] || at_eof[s])) v.push_back(bos);
         v.insert(v.end(), ids.begin() + (long)id_off[first_chunk[s]], ids.begin() + (long)id_off[first_chunk[s + 1]]);
-        if (o.enc.EOS && at_eof[s]) v.push_back(eos);
+        if (o.enc.EOS && !no_eos && at_eof[s]) v.push_back(eos);
     }
     return e;
 }

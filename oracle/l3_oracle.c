@@ -368,6 +368,14 @@ static int special_token_name(int idx, char* out) {
 }
 
 l3o_tokenizer* l3o_new(const char* vocab_b64, size_t vocab_len, const char* merges_b64, size_t merges_len) {
+    return l3o_new_special(vocab_b64, vocab_len, merges_b64, merges_len, NULL, 0);
+}
+
+/* New(WithSpecialTokens(list)) (options.go:17-37): config.specialTokens replaces getDefaultSpecialTokens() in
+ * tokenizer.go:194-198; everything else -- the split regex of the 256 default names included (tokenizer.go:27,232) --
+ * stays as it is.  specials == NULL: the defaults. */
+l3o_tokenizer* l3o_new_special(const char* vocab_b64, size_t vocab_len, const char* merges_b64, size_t merges_len,
+                               const char* const* specials, size_t n_specials) {
     uint8_t *vd = NULL, *md = NULL; size_t vn = 0, mn = 0;
     if (b64_decode(vocab_b64, vocab_len, &vd, &vn) != 0) return NULL;
     if (b64_decode(merges_b64, merges_len, &md, &mn) != 0) { free(vd); return NULL; }
@@ -377,8 +385,10 @@ l3o_tokenizer* l3o_new(const char* vocab_b64, size_t vocab_len, const char* merg
     /* DecodeVocabulary (decoder.go:16-36): split on '\n', drop empty strings; ID = index */
     size_t n_lines = 0;
     for (size_t i = 0; i < vn; i++) if (vd[i] == '\n') n_lines++;
-    t->tok_pool = (uint8_t*)malloc(vn + 256 * 40);
-    t->tok_off = (uint32_t*)malloc((n_lines + 2 + 256 + 1) * sizeof(uint32_t));
+    size_t n_sp = specials ? n_specials : 256, sp_bytes = 256 * 40;
+    if (specials) { sp_bytes = 0; for (size_t k = 0; k < n_specials; k++) sp_bytes += strlen(specials[k]); }
+    t->tok_pool = (uint8_t*)malloc(vn + sp_bytes + 16);
+    t->tok_off = (uint32_t*)malloc((n_lines + 2 + n_sp + 1) * sizeof(uint32_t));
     size_t pool = 0; int nt = 0; size_t s = 0;
     for (size_t i = 0; i <= vn; i++) {
         if (i == vn || vd[i] == '\n') {
@@ -387,9 +397,10 @@ l3o_tokenizer* l3o_new(const char* vocab_b64, size_t vocab_len, const char* merg
         }
     }
     /* special tokens appended (tokenizer.go:194-198) */
-    for (int k = 0; k < 256; k++) {
-        char name[48]; int l = special_token_name(k, name);
-        t->tok_off[nt] = (uint32_t)pool; memcpy(t->tok_pool + pool, name, (size_t)l); pool += (size_t)l; nt++;
+    for (size_t k = 0; k < n_sp; k++) {
+        char dflt[48]; const char* name = dflt; size_t l;
+        if (specials) { name = specials[k]; l = strlen(name); } else l = (size_t)special_token_name((int)k, dflt);
+        t->tok_off[nt] = (uint32_t)pool; memcpy(t->tok_pool + pool, name, l); pool += l; nt++;
     }
     t->tok_off[nt] = (uint32_t)pool;
     t->n_tokens = nt;

@@ -21,6 +21,10 @@ typedef struct l3o_tokenizer l3o_tokenizer;
 
 /* llama3.New() with the embedded data files' contents (tokenizer.go:142-213). NULL on bad data. */
 l3o_tokenizer* l3o_new(const char* vocab_b64, size_t vocab_len, const char* merges_b64, size_t merges_len);
+/* llama3.New(llama3.WithSpecialTokens(list)) (options.go:17-37; tokenizer.go:194-198): the list replaces the 256 default
+ * special tokens; specials == NULL: the defaults. */
+l3o_tokenizer* l3o_new_special(const char* vocab_b64, size_t vocab_len, const char* merges_b64, size_t merges_len,
+                               const char* const* specials, size_t n_specials);
 void l3o_free(l3o_tokenizer* t);
 /* Enable/disable the pre-token -> ids memo (bpe/cache.go SimpleCache; on by default as in New()). */
 void l3o_set_cache(l3o_tokenizer* t, int enabled);

@@ -65,6 +65,18 @@ void* l3h_new(int device, const char* data_dir, int* err_kind) {
     if (err_kind) *err_kind = (int)e.kind;
     return t.release();
 }
+// New(WithSpecialTokens(list)): names = n NUL-terminated strings
+void* l3h_new_special(int device, const char* data_dir, const char* const* names, int n, int* err_kind) {
+    Error e;
+    std::vector<Option> opts{WithDevice(device)};
+    if (data_dir) opts.push_back(WithDataFiles(std::string(data_dir) + "/vocab_base64.txt", std::string(data_dir) + "/merges_binary.txt"));
+    std::vector<std::string> list;
+    for (int i = 0; i < n; i++) list.push_back(names[i]);
+    opts.push_back(WithSpecialTokens(list));
+    std::unique_ptr<Tokenizer> t = New(opts, &e);
+    if (err_kind) *err_kind = (int)e.kind;
+    return t.release();
+}
 void l3h_free(void* h) { delete (Tokenizer*)h; }
 
 static long long copy_out(const std::vector<int>& v, int* out, long long cap) {
@@ -129,6 +141,18 @@ long long l3h_process(void* h, const uint8_t* data, long long n, int bos, int eo
     long long cnt = ((Tokenizer*)h)->Process(&r, &w, o);
     memcpy(out, w.v.data(), w.v.size() < (size_t)cap ? w.v.size() : (size_t)cap);
     return cnt;
+}
+// TokenStream over a controlled reader: the consumer takes `take` tokens (all when negative) and then drops the
+// stream; returns the count taken, -1 on a reader error seen after the channel closed
+long long l3h_token_stream(void* h, const uint8_t* data, long long n, const int* sizes, int n_sizes, long long take, int* out,
+                           long long cap) {
+    ControlledReader r(data, (size_t)n, sizes, n_sizes);
+    std::unique_ptr<TokenChannel> ch = ((Tokenizer*)h)->TokenStream(&r);
+    long long k = 0;
+    int tok = 0;
+    while ((take < 0 || k < take) && ch->Next(&tok)) { if (k < cap) out[k] = tok; k++; }
+    if (take >= 0 && k == take) return k;  // dropped early: the destructor unblocks and joins the producer
+    return ch->Err() ? -1 : k;
 }
 // many streams through one batch call; out = concatenated ids, out_off = n_streams + 1 offsets
 long long l3h_streams(void* h, const uint8_t* data, const long long* off, int n_streams, int buf_size, int bos, int eos,

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tokenizer_amd", "lib", "libl3hostapi.so")
 DATA = os.path.join(ROOT, "tokenizer_amd", "data")
 
-ERR_NONE, ERR_DATA_NOT_FOUND, ERR_INVALID_TOKEN, ERR_TOKEN_NOT_FOUND, ERR_DEVICE, ERR_READER = range(6)
+ERR_NONE, ERR_DATA_NOT_FOUND, ERR_INVALID_TOKEN, ERR_TOKEN_NOT_FOUND, ERR_DEVICE, ERR_READER, ERR_CONFIG = range(7)
 
 _P = C.c_void_p
 _LL = C.c_longlong
@@ -28,6 +28,10 @@ def load():
         L.l3h_chunks.argtypes = [_P, _LL, _P, C.c_int, C.c_int, C.c_int, _P, _P, _LL]
         L.l3h_new.restype = _P
         L.l3h_new.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+        L.l3h_new_special.restype = _P
+        L.l3h_new_special.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
+        L.l3h_token_stream.restype = _LL
+        L.l3h_token_stream.argtypes = [_P, _P, _LL, _P, C.c_int, _LL, _P, _LL]
         L.l3h_free.argtypes = [_P]
         L.l3h_encode.restype = _LL
         L.l3h_encode.argtypes = [_P, C.c_char_p, _LL, C.c_int, C.c_int, C.c_int, _P, _LL]
@@ -79,10 +83,15 @@ def chunks(data: bytes, read_sizes=None, buf_size=0, max_buffer=0):
 class Tokenizer:
     """llama3::Tokenizer (needs a GPU)."""
 
-    def __init__(self, device=0, data_dir=DATA):
+    def __init__(self, device=0, data_dir=DATA, specials=None):
+        """specials: list of bytes -> New(WithSpecialTokens(list))"""
         self.L = load()
         k = C.c_int(0)
-        self.h = self.L.l3h_new(device, data_dir.encode() if data_dir else None, C.byref(k))
+        if specials is None:
+            self.h = self.L.l3h_new(device, data_dir.encode() if data_dir else None, C.byref(k))
+        else:
+            arr = (C.c_char_p * max(len(specials), 1))(*specials)
+            self.h = self.L.l3h_new_special(device, data_dir.encode() if data_dir else None, arr, len(specials), C.byref(k))
         self.err_kind = k.value
         if not self.h:
             raise RuntimeError("llama3::New failed, error kind %d" % k.value)
@@ -145,6 +154,16 @@ class Tokenizer:
         out = np.empty(cap, dtype=np.int32)
         n = self.L.l3h_scan(self.h, d.ctypes.data if d.size else None, len(data), ap, an, buf_size, max_buffer,
                             int(opts[0]), int(opts[1]), out.ctypes.data, cap)
+        return None if n < 0 else out[:n].tolist()
+
+    def token_stream(self, data: bytes, read_sizes=None, take=-1):
+        """Tokens received from TokenStream's channel (all, or the first `take` before the stream is dropped);
+        None on a reader error."""
+        d = np.frombuffer(data, dtype=np.uint8)
+        a, ap, an = _sizes(read_sizes)
+        cap = len(data) * 3 + 16
+        out = np.empty(cap, dtype=np.int32)
+        n = self.L.l3h_token_stream(self.h, d.ctypes.data if d.size else None, len(data), ap, an, take, out.ctypes.data, cap)
         return None if n < 0 else out[:n].tolist()
 
     def process(self, data: bytes, opts=(False, False)):

@@ -24,8 +24,9 @@ def build_oracle():
 
 
 class Oracle:
-    def __init__(self, vocab=None, merges=None):
-        """vocab / merges: the contents of custom data files (WithDataFiles); default: the shipped Llama-3 files."""
+    def __init__(self, vocab=None, merges=None, specials=None):
+        """vocab / merges: the contents of custom data files (WithDataFiles); default: the shipped Llama-3 files.
+        specials: list of bytes, the special-token list of WithSpecialTokens (replaces the 256 defaults)."""
         self.lib = C.CDLL(build_oracle())
         L = self.lib
         L.l3o_new.restype = C.c_void_p
@@ -54,7 +55,13 @@ class Oracle:
         if vocab is None or merges is None:
             vocab = open(os.path.join(DATA, "vocab_base64.txt"), "rb").read()
             merges = open(os.path.join(DATA, "merges_binary.txt"), "rb").read()
-        self.h = L.l3o_new(vocab, len(vocab), merges, len(merges))
+        if specials is None:
+            self.h = L.l3o_new(vocab, len(vocab), merges, len(merges))
+        else:
+            L.l3o_new_special.restype = C.c_void_p
+            L.l3o_new_special.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t]
+            arr = (C.c_char_p * max(len(specials), 1))(*specials)
+            self.h = L.l3o_new_special(vocab, len(vocab), merges, len(merges), arr, len(specials))
         assert self.h, "oracle failed to load the vocabulary data"
 
     def encode(self, text: bytes, bos=True, eos=True):
@@ -95,6 +102,11 @@ class Oracle:
         out = np.empty(cap, dtype=np.uint8)
         n = self.lib.l3o_decode(self.h, a.ctypes.data, a.size, out.ctypes.data, cap)
         return out[:n].tobytes()
+
+    def vocab_size(self):
+        self.lib.l3o_vocab_size.restype = C.c_int
+        self.lib.l3o_vocab_size.argtypes = [C.c_void_p]
+        return self.lib.l3o_vocab_size(self.h)
 
     def rune_class(self, cp):
         return self.lib.l3o_rune_class(cp)

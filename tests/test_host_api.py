@@ -295,3 +295,43 @@ def test_many_streams_one_batch(tok, oracle):
         got = tok.streams(streams, buf_size=256, opts=opts)
         for s, g in zip(streams, got):
             assert g == tok.scan(s, buf_size=256, opts=opts) == _expected_scan(oracle, s, (), 256, 1 << 20, opts)
+
+
+@pytest.mark.gpu
+def test_token_stream_channel(tok, oracle):
+    # llama3/scanner.go:107-132 (scanner_test.go TestTokenStream): the tokens of NewScanner(r) -- no BOS/EOS -- through a
+    # channel of 100; more than 100 tokens exercises the blocking sender, `take` drops the stream while it is blocked
+    for text in [b"Hello world", b"", ("test " * 1000).encode(), (FOX * 50).encode()]:
+        assert tok.token_stream(text) == _expected_scan(oracle, text)
+    big = ("word " * 5000).encode()
+    want = _expected_scan(oracle, big)
+    assert len(want) > 1000
+    assert tok.token_stream(big, take=7) == want[:7]
+    assert tok.token_stream(big, take=0) == []
+    assert tok.token_stream(b"", [-1]) is None                    # the reader's error arrives on the error channel
+    assert tok.token_stream(big, [64, 64, -1]) is None
+
+
+@pytest.mark.gpu
+def test_new_with_special_tokens(oracle):
+    # options.go:17-37 + tokenizer.go:151-155: a bad list fails New with a ConfigError; a good one replaces the defaults
+    from tests.oracle import Oracle
+    for bad in ([b"<|test|>", b"invalid"], [b"<|test|>", b"<|test|>"], [b"<||>"]):
+        with pytest.raises(RuntimeError, match="error kind %d" % hostapi.ERR_CONFIG):
+            hostapi.Tokenizer(0, specials=bad)
+    names = [b"<|begin_of_text|>", b"<|my_tok|>", b"<|start_header_id|>"]
+    t, o = hostapi.Tokenizer(0, specials=names), Oracle(specials=names)
+    try:
+        assert t.vocab_size() == 128003
+        assert t.special(b"<|my_tok|>") == (128001, hostapi.ERR_NONE)
+        assert t.special(b"<|end_of_text|>")[1] == hostapi.ERR_TOKEN_NOT_FOUND
+        assert t.special(b"<|>")[1] == hostapi.ERR_TOKEN_NOT_FOUND          # tokens/special.go:43-45: prefix and suffix may overlap
+        text = b"Hello <|start_header_id|>user<|eot_id|> <|my_tok|>"
+        assert t.encode(text) == o.encode(text, True, True) and t.encode(text)[0] == 128000 and t.encode(text)[-1] != 128001
+        # the scanner adds BOS / EOS through GetSpecialTokenID too (scanner.go:188,195,232): no <|end_of_text|>, no EOS
+        assert t.scan(b"hi there", opts=(True, True)) == o.encode(b"hi there", True, False)
+        assert t.scan(b"", opts=(True, True)) == [128000]
+        assert t.streams([b"hi there", b""], opts=(True, True)) == [o.encode(b"hi there", True, False), [128000]]
+        assert t.decode([128001, 128002]) == b"<|my_tok|><|start_header_id|>"
+    finally:
+        t.close()

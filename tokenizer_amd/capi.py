@@ -30,6 +30,7 @@ L3_NO_SPECIAL = 4
 _P = C.c_void_p
 SYMBOLS = [
     ("l3_create", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_int, C.POINTER(_P)]),
+    ("l3_create_ex", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.POINTER(_P)]),
     ("l3_destroy", None, [_P]),
     ("l3_last_error", C.c_char_p, [_P]),
     ("l3_encode_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
@@ -104,12 +105,17 @@ def pack_docs(docs):
 class Context:
     """One l3_ctx: the tables of one tokenizer on one GPU."""
 
-    def __init__(self, device=0, vocab=None, merges=None):
+    def __init__(self, device=0, vocab=None, merges=None, specials=None):
+        """specials: list of bytes -- the special-token list of WithSpecialTokens (l3_create_ex); None: the defaults"""
         self.lib = load_library()
         if vocab is None or merges is None:
             vocab, merges = read_data_files()
         h = _P()
-        rc = self.lib.l3_create(vocab, len(vocab), merges, len(merges), device, C.byref(h))
+        if specials is None:
+            rc = self.lib.l3_create(vocab, len(vocab), merges, len(merges), device, C.byref(h))
+        else:
+            arr = (C.c_char_p * max(len(specials), 1))(*specials)
+            rc = self.lib.l3_create_ex(vocab, len(vocab), merges, len(merges), arr, len(specials), device, C.byref(h))
         if rc != L3_OK:
             raise L3Error(rc, (self.lib.l3_last_error(None) or b"").decode("utf-8", "replace"))
         self.h = h

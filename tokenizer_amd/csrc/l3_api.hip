@@ -250,8 +250,8 @@ int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W)
     const size_t need = carve_workspace(nullptr, n_bytes, n_docs, K, nullptr, W);
     HIPCHK(c, c->w_arena.ensure(need));
     carve_workspace(c->w_arena.as<uint8_t>(), n_bytes, n_docs, K, c->w_status.as<Status>(), W);
-    W.bos_id = c->H.special_id[0];  // canonical index 0 / 1 = <|begin_of_text|> / <|end_of_text|> (l3_tables.cpp)
-    W.eos_id = c->H.special_id[1];
+    W.bos_id = c->H.bos_id;   // (looked up, not constants: tokenizer.go:226,259)
+    W.eos_id = c->H.eos_id;
     W.slow_grid = c->slow_grid;
     return L3_OK;
 }
@@ -450,11 +450,26 @@ extern "C" {
 
 int l3_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len, int device,
               l3_ctx** out) {
+    return l3_create_ex(vocab_b64, vocab_len, merges_b64, merges_len, nullptr, 0, device, out);
+}
+
+int l3_create_ex(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len,
+                 const char* const* special_tokens, size_t n_special, int device, l3_ctx** out) {
     if (!out) return L3_E_INVALID_ARG;
     *out = nullptr;
     if (!vocab_b64 || !merges_b64) { g_create_err = "null data pointer"; return L3_E_INVALID_ARG; }
+    std::vector<std::string> specials;
+    if (special_tokens) {   // WithSpecialTokens (options.go:17-37): "<|...|>", at least five bytes, no duplicates
+        for (size_t i = 0; i < n_special; i++) {
+            const std::string t = special_tokens[i] ? special_tokens[i] : "";
+            bool ok = t.size() >= 5 && t.compare(0, 2, "<|") == 0 && t.compare(t.size() - 2, 2, "|>") == 0;
+            for (size_t j = 0; ok && j < specials.size(); j++) ok = specials[j] != t;
+            if (!ok) { g_create_err = "special token \"" + t + "\": must be <|...|> and must not repeat"; return L3_E_INVALID_ARG; }
+            specials.push_back(t);
+        }
+    }
     l3_ctx* c = new l3_ctx();
-    if (!build_tables(vocab_b64, vocab_len, merges_b64, merges_len, c->H)) {
+    if (!build_tables(vocab_b64, vocab_len, merges_b64, merges_len, c->H, special_tokens ? &specials : nullptr)) {
         g_create_err = c->H.error;
         delete c;
         return L3_E_DATA;
@@ -498,7 +513,7 @@ int l3_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, s
     }
     int rc = upload_tables(c);
     if (rc) return fail(rc);
-    for (int i = 0; i < kNumSpecial; i++) c->special_by_name[special_name(i)] = c->H.special_id[i];
+    for (size_t i = 0; i < c->H.special_names.size(); i++) c->special_by_name[c->H.special_names[i]] = c->H.n_base + (int)i;
     *out = c;
     return L3_OK;
 }
@@ -535,6 +550,13 @@ void l3_destroy(l3_ctx* c) {
 
 const char* l3_last_error(const l3_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+// BOS / EOS are only added if the tokenizer has such a token: with a custom special-token list that lacks it
+// GetSpecialTokenID fails and Encode adds nothing (tokenizer.go:225-229,258-262)
+static uint32_t effective_flags(const l3_ctx* c, uint32_t flags) {
+    if (c->H.bos_id < 0) flags &= ~L3_BOS;
+    if (c->H.eos_id < 0) flags &= ~L3_EOS;
+    return flags;
+}
 // flags are L3_BOS | L3_EOS | L3_NO_SPECIAL
 static bool bad_flags(l3_ctx* c, uint32_t flags) {
     if (flags & ~(L3_BOS | L3_EOS | L3_NO_SPECIAL)) { c->err = "unknown bits in flags"; return true; }
@@ -553,7 +575,7 @@ int l3_encode_batch_device(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, c
     if (bad_flags(c, flags)) return L3_E_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     EncodeArgs A{};
-    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = flags;
+    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = effective_flags(c, flags);
     A.out_tok = d_out_tok; A.out_cap = out_cap; A.out_off = d_out_off; A.kinds = nullptr;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     int rc = encode_core(c, A, s, n_tok, nullptr);
@@ -608,7 +630,7 @@ int l3_encode_submit(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, const u
     int rc = ensure_workspace(c, n_bytes, n_docs, W);
     if (rc) return rc;
     EncodeArgs A{};
-    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = flags;
+    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = effective_flags(c, flags);
     A.out_tok = d_out_tok; A.out_cap = out_cap; A.out_off = d_out_off; A.kinds = nullptr;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if ((rc = order_behind_last(c, s))) return rc;
@@ -699,11 +721,11 @@ int l3_encode_batch_device_noalloc(l3_ctx* c, const uint8_t* d_text, uint64_t n_
     const size_t status_bytes = (sizeof(Status) + 255) & ~(size_t)255;
     const size_t need = status_bytes + carve_workspace(base + status_bytes, n_bytes, n_docs, K, status, W);
     if (need > kNoAllocScratchBytes) { c->err = "internal: static workspace too small for its own limits"; return L3_E_INVALID_ARG; }
-    W.bos_id = c->H.special_id[0];
-    W.eos_id = c->H.special_id[1];
+    W.bos_id = c->H.bos_id;
+    W.eos_id = c->H.eos_id;
     W.allow_giants = 0;   // the grid-wide merge of very long cut-free pieces allocates: here one workgroup merges each
     EncodeArgs A{};
-    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = flags;
+    A.text = d_text; A.n_bytes = n_bytes; A.doc_off = d_doc_off; A.n_docs = n_docs; A.flags = effective_flags(c, flags);
     A.out_tok = d_out_tok; A.out_cap = out_cap; A.out_off = d_out_off; A.kinds = nullptr;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     // the array keeps the previous call's contents: the status word (counters, flags, queues) must start at zero; every
@@ -804,7 +826,7 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[k], 0));
         EncodeArgs A{};
         A.text = c->s_text.as<uint8_t>() + b0; A.n_bytes = nb; A.doc_off = c->s_off.as<uint64_t>() + rel0[k]; A.n_docs = nd;
-        A.flags = flags; A.out_tok = ob.as<int32_t>(); A.out_cap = ob.cap / 4; A.out_off = oo.as<uint64_t>(); A.kinds = nullptr;
+        A.flags = effective_flags(c, flags); A.out_tok = ob.as<int32_t>(); A.out_cap = ob.cap / 4; A.out_off = oo.as<uint64_t>(); A.kinds = nullptr;
         Workspace W{};
         uint64_t tk = 0;
         int rc = encode_core(c, A, c->stream, &tk, &W);
@@ -857,7 +879,7 @@ int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uin
     HIPCHK(c, hipMemcpyAsync(c->s_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s));
     EncodeArgs A{};
     A.text = c->s_text.as<uint8_t>(); A.n_bytes = n_bytes; A.doc_off = c->s_off.as<uint64_t>(); A.n_docs = n_docs;
-    A.flags = flags; A.out_tok = c->s_out.as<int32_t>(); A.out_cap = c->s_out.cap / 4;
+    A.flags = effective_flags(c, flags); A.out_tok = c->s_out.as<int32_t>(); A.out_cap = c->s_out.cap / 4;
     A.out_off = c->s_outoff.as<uint64_t>(); A.kinds = nullptr;
     Workspace W{};
     uint64_t total = 0;

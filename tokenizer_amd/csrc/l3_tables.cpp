@@ -111,7 +111,8 @@ int special_default_id(int i) {
     return 128008 + k;
 }
 
-bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len, HostTables& T) {
+bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len, HostTables& T,
+                  const std::vector<std::string>* specials) {
     std::vector<uint8_t> vtxt, mbin;
     if (!vocab_b64 || !b64_decode((const uint8_t*)vocab_b64, vocab_len, vtxt) || vtxt.empty()) {
         T.error = "decode vocabulary base64"; return false;
@@ -147,21 +148,37 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
         i = e + 1;
     }
     int n_base = (int)T.tok_off.size();
-    if (n_base < 256 || n_base > (1 << 17) - kNumSpecial) { T.error = "unsupported vocabulary size"; return false; }
-    // special tokens are appended after the base vocabulary (tokenizer.go:194-198)
-    for (int k = 0; k < kNumSpecial; k++) T.special_id[k] = 0;
-    {
-        // list order of GetDefaultSpecialTokens: invert special_default_id
-        std::vector<std::string> by_list(kNumSpecial);
-        for (int c = 0; c < kNumSpecial; c++) by_list[special_default_id(c) - 128000] = special_name(c);
-        for (int k = 0; k < kNumSpecial; k++) {
-            T.tok_off.push_back((uint32_t)T.tok_bytes.size());
-            T.tok_bytes.insert(T.tok_bytes.end(), by_list[k].begin(), by_list[k].end());
-        }
-        for (int c = 0; c < kNumSpecial; c++) T.special_id[c] = n_base + (special_default_id(c) - 128000);
+    // special tokens are appended after the base vocabulary (tokenizer.go:194-198): the defaults in the order of
+    // GetDefaultSpecialTokens (special.go:19-40), or the caller's list in its place
+    T.special_names.clear();
+    if (specials) {
+        T.special_names = *specials;
+    } else {
+        T.special_names.resize(kNumSpecial);
+        for (int c = 0; c < kNumSpecial; c++) T.special_names[special_default_id(c) - 128000] = special_name(c);
     }
+    const int n_special = (int)T.special_names.size();
+    if (n_base < 256 || n_base + n_special > (1 << 17)) { T.error = "unsupported vocabulary size"; return false; }
+    T.n_base = n_base;
+    std::unordered_map<std::string, int> special_lookup;
+    for (int k = 0; k < n_special; k++) {
+        T.tok_off.push_back((uint32_t)T.tok_bytes.size());
+        T.tok_bytes.insert(T.tok_bytes.end(), T.special_names[k].begin(), T.special_names[k].end());
+        special_lookup[T.special_names[k]] = n_base + k;   // (later duplicates win, as in tokenizer.go:201-204)
+    }
+    // tokenLookup[name] for a name (tokenizer.go:236,357-368): the special list first (its ids are the later ones), then a
+    // vocabulary entry that happens to spell it; 0 / -1 if there is none
+    auto lookup_name = [&](const std::string& name) {
+        auto it = special_lookup.find(name);
+        if (it != special_lookup.end()) return it->second;
+        auto ib = by_bytes.find(name);
+        return ib != by_bytes.end() ? ib->second : -1;
+    };
+    for (int c = 0; c < kNumSpecial; c++) { const int id = lookup_name(special_name(c)); T.special_id[c] = id > 0 ? id : 0; }
+    T.bos_id = lookup_name("<|begin_of_text|>");
+    T.eos_id = lookup_name("<|end_of_text|>");
     T.tok_off.push_back((uint32_t)T.tok_bytes.size());
-    T.n_tokens = n_base + kNumSpecial;
+    T.n_tokens = n_base + n_special;
     auto tok = [&](int id) { return std::string((const char*)T.tok_bytes.data() + T.tok_off[id], T.tok_off[id + 1] - T.tok_off[id]); };
 
     // ---- single-byte tokens

@@ -32,12 +32,19 @@ struct HostTables {
     std::vector<uint32_t> tok_off;  // n_tokens + 1
     int n_tokens = 0;
     int n_merges = 0;
+    int n_base = 0;                          // tokens of the vocabulary file; the special tokens follow (tokenizer.go:194-198)
+    std::vector<std::string> special_names;  // ... in id order: the 256 defaults, or the list of WithSpecialTokens
+    int32_t bos_id = -1, eos_id = -1;        // ids of <|begin_of_text|> / <|end_of_text|>, -1: not in the list (then Encode adds none,
+                                             // tokenizer.go:225-229,258-262: GetSpecialTokenID fails)
     std::string error;
 };
 
 // Returns false and sets out.error on malformed or unsupported data.
+// `specials` (optional): the special-token list of WithSpecialTokens (options.go:17-37), which REPLACES the 256 defaults;
+// ids follow the vocabulary in list order.  The split of the text stays at the 256 default names (tokenizer.go:27,232); a
+// default name that is not in the list is ordinary text (its lookup is 0, tokenizer.go:236).
 bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len,
-                  HostTables& out);
+                  HostTables& out, const std::vector<std::string>* specials = nullptr);
 
 // Name of the special token with canonical index i (0..255) and its default id.
 std::string special_name(int canonical_index);
