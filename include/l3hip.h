@@ -140,6 +140,28 @@ int l3_timing_totals(l3_ctx* ctx, double* ms, int cap, uint64_t* calls);
  * and more that no cut divides) */
 int l3_last_counters(l3_ctx* ctx, uint64_t* out, int cap);
 
+/* ---- several GPUs behind one handle --------------------------------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE (its only concurrent workload is goroutines calling Encode on one Tokenizer,
+ * benchmark_test.go:151-174).  One context per entry of devices[] (a device may be named more than once); a batch is cut
+ * into one contiguous range of documents per context, balanced by bytes, each range is encoded on its GPU by a host thread
+ * of its own, and the results come back concatenated in document order -- identical to l3_encode_batch on one context.
+ * special_tokens / n_special as in l3_create_ex (NULL: the defaults). */
+typedef struct l3_multi l3_multi;
+int l3_multi_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len,
+                    const char* const* special_tokens, size_t n_special, const int* devices, int n_dev, l3_multi** out);
+void l3_multi_destroy(l3_multi* m);
+int l3_multi_size(const l3_multi* m);
+/* context i, for everything that is not sharded (l3_special_token_id, l3_vocab_size, l3_decode_batch, counters, ...);
+ * owned by the handle */
+l3_ctx* l3_multi_context(l3_multi* m, int i);
+const char* l3_multi_last_error(const l3_multi* m);
+/* Same arguments, results and capacity protocol as l3_encode_batch. */
+int l3_multi_encode_batch(l3_multi* m, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                          int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok);
+/* The partition l3_multi_encode_batch uses (host arithmetic only): cuts[0..world], shard r = documents
+ * [cuts[r], cuts[r+1]); cuts[r] is the first document that starts at or after r/world of the bytes. */
+int l3_partition_by_bytes(const uint64_t* doc_off, uint64_t n_docs, int world, uint64_t* cuts);
+
 #ifdef __cplusplus
 }
 #endif

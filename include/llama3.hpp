@@ -11,6 +11,7 @@
 //   Tokenizer::OptimisticCount                tokenizer.go:370-417
 //   Tokenizer::VocabSize / PreTokenize        tokenizer.go:420-422,490-504
 //   Tokenizer::EncodeBatch                    new, additive: the batched hot path
+//   WithDevices                               new, additive: EncodeBatch shards its documents over several GPUs (l3_multi_*)
 //   scanner::Tokenizer, scanner::New/NewWithOptions, Scanner::Scan/Token/Text/Err
 //                                             llama3/scanner/scanner.go:12-111,241-333 (chunking rules :124-181,337-478)
 //   Tokenizer::NewScanner / Process           llama3/scanner.go:67-102 (Process writes uint32 little-endian)
@@ -55,6 +56,7 @@ struct EncodeOptions {  // tokenizer.go:107-112
 struct Config {
     std::string vocabPath, mergesPath;  // WithDataFiles
     int device = 0;                     // new: which GPU holds the tables
+    std::vector<int> devices;           // new: WithDevices -- batches are sharded over these GPUs
     bool haveSpecials = false;          // WithSpecialTokens with a non-nil list (an empty one counts: no special tokens)
     std::vector<std::string> specialTokens;
     Error err;                          // the first option that failed (New returns it, tokenizer.go:151-155)
@@ -65,7 +67,9 @@ struct Option {
     int i = 0;
     int which = 0;
     std::vector<std::string> list;
+    std::vector<int> ints;
     void Apply(Config& c) const {
+        if (which == 4) c.devices = ints;
         if (which == 1) { c.vocabPath = a; c.mergesPath = b; }
         if (which == 2) c.device = i;
         if (which == 3) {  // options.go:19-33: each name is <|...|> of at least 5 bytes, and none appears twice
@@ -90,6 +94,9 @@ inline Option WithDataFiles(const std::string& vocabPath, const std::string& mer
     Option o; o.which = 1; o.a = vocabPath; o.b = mergesPath; return o;
 }
 inline Option WithDevice(int device) { Option o; o.which = 2; o.i = device; return o; }
+// One context per entry; EncodeBatch (and everything built on it) cuts a batch into byte-balanced ranges of documents, one per
+// GPU.  Single-document calls and Decode use the first device.
+inline Option WithDevices(const std::vector<int>& devices) { Option o; o.which = 4; o.ints = devices; return o; }
 // options.go:17-37.  Go's nil slice (keep the defaults) is "do not pass the option" here.
 inline Option WithSpecialTokens(const std::vector<std::string>& tokens) { Option o; o.which = 3; o.list = tokens; return o; }
 
@@ -372,7 +379,10 @@ class TokenChannel {
 // ---- the tokenizer ------------------------------------------------------------------------------------
 class Tokenizer : public scanner::Tokenizer {
   public:
-    ~Tokenizer() override { if (ctx_) l3_destroy(ctx_); }
+    ~Tokenizer() override {
+        if (multi_) l3_multi_destroy(multi_);   // owns every context, ctx_ included
+        else if (ctx_) l3_destroy(ctx_);
+    }
     Tokenizer(const Tokenizer&) = delete;
     Tokenizer& operator=(const Tokenizer&) = delete;
 
@@ -400,9 +410,13 @@ class Tokenizer : public scanner::Tokenizer {
         id_off->resize((size_t)n_docs + 1);
         for (;;) {
             uint64_t n = 0;
-            int rc = l3_encode_batch(ctx_, text, off.data(), n_docs, flagsOf(opts), ids->data(), ids->size(), id_off->data(), &n);
+            int rc = multi_ ? l3_multi_encode_batch(multi_, text, off.data(), n_docs, flagsOf(opts), ids->data(), ids->size(), id_off->data(), &n)
+                            : l3_encode_batch(ctx_, text, off.data(), n_docs, flagsOf(opts), ids->data(), ids->size(), id_off->data(), &n);
             if (rc == L3_E_OUTPUT_CAP) { ids->resize((size_t)n); continue; }
-            if (rc != L3_OK) { e.kind = ErrKind::Device; e.op = "encode"; e.detail = l3_last_error(ctx_); last_ = e; ids->clear(); return e; }
+            if (rc != L3_OK) {
+                e.kind = ErrKind::Device; e.op = "encode"; e.detail = multi_ ? l3_multi_last_error(multi_) : l3_last_error(ctx_);
+                last_ = e; ids->clear(); return e;
+            }
             ids->resize((size_t)n);
             return e;
         }
@@ -473,7 +487,10 @@ class Tokenizer : public scanner::Tokenizer {
                 break;
             }
         }
-        return (int)(n_tok + matches + 2);
+        Error no_bos, no_eos;  // counted only when the tokenizer has them (tokenizer.go:378-380,412-414)
+        GetSpecialTokenID("<|begin_of_text|>", &no_bos);
+        GetSpecialTokenID("<|end_of_text|>", &no_eos);
+        return (int)(n_tok + matches + (no_bos ? 0 : 1) + (no_eos ? 0 : 1));
     }
     int VocabSize() const { return l3_vocab_size(ctx_); }  // tokenizer.go:420-422
     // PreTokenize (tokenizer.go:490-506): the pieces of pretokenizer.Tokenize(text) -- which knows no special
@@ -562,6 +579,7 @@ class Tokenizer : public scanner::Tokenizer {
         dst->insert(dst->end(), ids.begin(), ids.end());
     }
     l3_ctx* ctx_ = nullptr;
+    l3_multi* multi_ = nullptr;
     Error last_;
 };
 
@@ -597,14 +615,16 @@ inline std::unique_ptr<Tokenizer> New(const std::vector<Option>& opts, Error* er
     }
     std::unique_ptr<Tokenizer> t(new Tokenizer());
     int rc;
-    if (c.haveSpecials) {
-        std::vector<const char*> names;
-        for (const std::string& n : c.specialTokens) names.push_back(n.c_str());
-        static const char* const none[1] = {nullptr};
-        rc = l3_create_ex(vocab.data(), vocab.size(), merges.data(), merges.size(), names.empty() ? none : names.data(), names.size(),
-                          c.device, &t->ctx_);
+    std::vector<const char*> names;
+    for (const std::string& n : c.specialTokens) names.push_back(n.c_str());
+    static const char* const none[1] = {nullptr};
+    const char* const* sp = !c.haveSpecials ? nullptr : names.empty() ? none : names.data();
+    if (!c.devices.empty()) {
+        rc = l3_multi_create(vocab.data(), vocab.size(), merges.data(), merges.size(), sp, names.size(), c.devices.data(),
+                             (int)c.devices.size(), &t->multi_);
+        if (rc == L3_OK) t->ctx_ = l3_multi_context(t->multi_, 0);
     } else {
-        rc = l3_create(vocab.data(), vocab.size(), merges.data(), merges.size(), c.device, &t->ctx_);
+        rc = l3_create_ex(vocab.data(), vocab.size(), merges.data(), merges.size(), sp, names.size(), c.device, &t->ctx_);
     }
     if (rc != L3_OK) {
         if (err) { err->kind = rc == L3_E_DATA ? ErrKind::DataNotFound : ErrKind::Device; err->op = "l3_create"; err->detail = l3_last_error(nullptr); }

@@ -77,6 +77,15 @@ void* l3h_new_special(int device, const char* data_dir, const char* const* names
     if (err_kind) *err_kind = (int)e.kind;
     return t.release();
 }
+// New(WithDevices(devices))
+void* l3h_new_devices(const int* devices, int n, const char* data_dir, int* err_kind) {
+    Error e;
+    std::vector<Option> opts{WithDevices(std::vector<int>(devices, devices + n))};
+    if (data_dir) opts.push_back(WithDataFiles(std::string(data_dir) + "/vocab_base64.txt", std::string(data_dir) + "/merges_binary.txt"));
+    std::unique_ptr<Tokenizer> t = New(opts, &e);
+    if (err_kind) *err_kind = (int)e.kind;
+    return t.release();
+}
 void l3h_free(void* h) { delete (Tokenizer*)h; }
 
 static long long copy_out(const std::vector<int>& v, int* out, long long cap) {

@@ -30,6 +30,8 @@ def load():
         L.l3h_new.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_int)]
         L.l3h_new_special.restype = _P
         L.l3h_new_special.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
+        L.l3h_new_devices.restype = _P
+        L.l3h_new_devices.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_char_p, C.POINTER(C.c_int)]
         L.l3h_token_stream.restype = _LL
         L.l3h_token_stream.argtypes = [_P, _P, _LL, _P, C.c_int, _LL, _P, _LL]
         L.l3h_free.argtypes = [_P]
@@ -83,11 +85,14 @@ def chunks(data: bytes, read_sizes=None, buf_size=0, max_buffer=0):
 class Tokenizer:
     """llama3::Tokenizer (needs a GPU)."""
 
-    def __init__(self, device=0, data_dir=DATA, specials=None):
-        """specials: list of bytes -> New(WithSpecialTokens(list))"""
+    def __init__(self, device=0, data_dir=DATA, specials=None, devices=None):
+        """specials: list of bytes -> New(WithSpecialTokens(list)); devices: list of ints -> New(WithDevices(list))"""
         self.L = load()
         k = C.c_int(0)
-        if specials is None:
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            self.h = self.L.l3h_new_devices(arr, len(devices), data_dir.encode() if data_dir else None, C.byref(k))
+        elif specials is None:
             self.h = self.L.l3h_new(device, data_dir.encode() if data_dir else None, C.byref(k))
         else:
             arr = (C.c_char_p * max(len(specials), 1))(*specials)

@@ -333,5 +333,22 @@ def test_new_with_special_tokens(oracle):
         assert t.scan(b"", opts=(True, True)) == [128000]
         assert t.streams([b"hi there", b""], opts=(True, True)) == [o.encode(b"hi there", True, False), [128000]]
         assert t.decode([128001, 128002]) == b"<|my_tok|><|start_header_id|>"
+        # OptimisticCount counts BOS / EOS only when the tokenizer has them (tokenizer.go:378-380,412-414)
+        assert t.optimistic_count(b"hi <|whatever|> there") == 1 + len(o.encode(b"hi ", False, False)) + 1 + len(o.encode(b" there", False, False))
+    finally:
+        t.close()
+
+
+@pytest.mark.gpu
+def test_with_devices_shards_streams(tok, oracle):
+    # WithDevices: the same API over several contexts (here three on device 0); EncodeStreams is one sharded batch
+    t = hostapi.Tokenizer(devices=[0, 0, 0])
+    try:
+        rng = random.Random(11)
+        words = ["alpha", "beta", " ", "\n", "世界", "1234567", "don't", "<|eot_id|>"]
+        streams = ["".join(rng.choice(words) for _ in range(rng.randrange(1, 600))).encode() for _ in range(30)]
+        assert t.streams(streams, buf_size=256, opts=(True, True)) == tok.streams(streams, buf_size=256, opts=(True, True))
+        assert t.encode(b"Hello world!") == oracle.encode(b"Hello world!", True, True)
+        assert t.decode([9906, 1917, 0]) == b"Hello world!" and t.vocab_size() == 128256
     finally:
         t.close()

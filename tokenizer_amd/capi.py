@@ -32,6 +32,14 @@ SYMBOLS = [
     ("l3_create", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_int, C.POINTER(_P)]),
     ("l3_create_ex", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.POINTER(_P)]),
     ("l3_destroy", None, [_P]),
+    ("l3_multi_create", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_int), C.c_int,
+                                  C.POINTER(_P)]),
+    ("l3_multi_destroy", None, [_P]),
+    ("l3_multi_size", C.c_int, [_P]),
+    ("l3_multi_context", _P, [_P, C.c_int]),
+    ("l3_multi_last_error", C.c_char_p, [_P]),
+    ("l3_multi_encode_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
+    ("l3_partition_by_bytes", C.c_int, [_P, C.c_uint64, C.c_int, _P]),
     ("l3_last_error", C.c_char_p, [_P]),
     ("l3_encode_batch", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     ("l3_encode_batch_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P,
@@ -269,3 +277,70 @@ class Context:
         self.lib.l3_last_counters(self.h, a.ctypes.data, 8)
         return dict(zip(["tiles", "slow_pretokens", "deferred_tokens", "scratch_bytes", "retries", "short_pretokens", "window_items",
                          "giant_symbols"], a.tolist()))
+
+
+def partition_by_bytes(doc_off, world):
+    """l3_partition_by_bytes: world + 1 document indices (host arithmetic only, no GPU needed)."""
+    lib = load_library()
+    doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+    cuts = np.zeros(world + 1, dtype=np.uint64)
+    rc = lib.l3_partition_by_bytes(doc_off.ctypes.data, doc_off.size - 1, world, cuts.ctypes.data)
+    if rc != L3_OK:
+        raise L3Error(rc, "l3_partition_by_bytes")
+    return cuts.astype(np.int64).tolist()
+
+
+class MultiContext:
+    """l3_multi: one context per entry of `devices`, batches sharded by document over them."""
+
+    def __init__(self, devices, vocab=None, merges=None, specials=None):
+        self.lib = load_library()
+        if vocab is None or merges is None:
+            vocab, merges = read_data_files()
+        h = _P()
+        dev = (C.c_int * len(devices))(*devices)
+        arr = None if specials is None else (C.c_char_p * max(len(specials), 1))(*specials)
+        rc = self.lib.l3_multi_create(vocab, len(vocab), merges, len(merges), arr, 0 if specials is None else len(specials),
+                                      dev, len(devices), C.byref(h))
+        if rc != L3_OK:
+            raise L3Error(rc, (self.lib.l3_multi_last_error(None) or b"").decode("utf-8", "replace"))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.l3_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return self.lib.l3_multi_size(self.h)
+
+    def last_counters(self, i):
+        out = (C.c_uint64 * 8)()
+        self.lib.l3_last_counters(self.lib.l3_multi_context(self.h, i), out, 8)
+        return list(out)
+
+    def encode_batch(self, text, doc_off, bos=True, eos=True, out_cap=None):
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text,
+                                    dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        n_docs = doc_off.size - 1
+        flags = (L3_BOS if bos else 0) | (L3_EOS if eos else 0)
+        cap = int(out_cap) if out_cap is not None else int(text.size) + 2 * n_docs + 64
+        while True:
+            out = np.empty(max(cap, 1), dtype=np.int32)
+            off = np.empty(n_docs + 1, dtype=np.uint64)
+            n = C.c_uint64(0)
+            rc = self.lib.l3_multi_encode_batch(self.h, text.ctypes.data, doc_off.ctypes.data, n_docs, flags, out.ctypes.data, cap,
+                                                off.ctypes.data, C.byref(n))
+            if rc == L3_E_OUTPUT_CAP and out_cap is None:
+                cap = int(n.value)
+                continue
+            if rc != L3_OK:
+                raise L3Error(rc, (self.lib.l3_multi_last_error(self.h) or b"").decode("utf-8", "replace"))
+            return out[:n.value], off

@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -856,19 +859,13 @@ static int encode_batch_pieces(l3_ctx* c, const uint8_t* text, const uint64_t* d
     return L3_OK;
 }
 
-int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
-                    int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok) {
-    if (!c) return L3_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (bad_flags(c, flags)) return L3_E_INVALID_ARG;
-    if (!doc_off || !out_off || !n_tok || (!out_tok && out_cap)) { c->err = "null pointer argument"; return L3_E_INVALID_ARG; }
-    int rc = check_offsets_host(c, doc_off, n_docs);
-    if (rc) return rc;
+// One host-fed batch in two steps, so that a caller that shards a batch over several contexts (l3_multi_encode_batch) can
+// place every shard's ids behind the ids of the shards before it without a second host copy: host_stage_encode uploads and
+// encodes and leaves ids and offsets in the context's staging buffers, host_stage_download copies them to their final place.
+// The context's mutex is held by the caller across both.
+static int host_stage_encode(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                             uint64_t* total) {
     const uint64_t n_bytes = doc_off[n_docs];
-    if (!text && n_bytes) { c->err = "null text"; return L3_E_INVALID_ARG; }
-    HIPCHK(c, hipSetDevice(c->device));
-    if (n_bytes >= (16ull << 20) && n_docs >= 16 && is_pinned(text) && is_pinned(out_tok))   // (pageable copies do not overlap)
-        return encode_batch_pieces(c, text, doc_off, n_docs, flags, out_tok, out_cap, out_off, n_tok);
     hipStream_t s = c->stream;
     HIPCHK(c, c->s_text.ensure(n_bytes + 16));
     HIPCHK(c, c->s_off.ensure((n_docs + 1) * 8));
@@ -882,24 +879,45 @@ int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uin
     A.flags = effective_flags(c, flags); A.out_tok = c->s_out.as<int32_t>(); A.out_cap = c->s_out.cap / 4;
     A.out_off = c->s_outoff.as<uint64_t>(); A.kinds = nullptr;
     Workspace W{};
-    uint64_t total = 0;
-    rc = encode_core(c, A, s, &total, &W);
+    int rc = encode_core(c, A, s, total, &W);
     if (rc == L3_E_OUTPUT_CAP) {  // our guess was too small: enlarge and redo only the final scatter
-        HIPCHK(c, c->s_out.ensure(total * 4));
+        HIPCHK(c, c->s_out.ensure(*total * 4));
         A.out_tok = c->s_out.as<int32_t>();
         A.out_cap = c->s_out.cap / 4;
         rc = rerun_emit(c, W, A, s);
     }
+    return rc;
+}
+
+// n_off offsets (n_docs, or n_docs + 1 with the closing one) and, when `with_tokens`, the ids
+static int host_stage_download(l3_ctx* c, uint64_t n_off, uint64_t total, bool with_tokens, int32_t* out_tok, uint64_t* out_off) {
+    hipStream_t s = c->stream;
+    if (n_off) HIPCHK(c, hipMemcpyAsync(out_off, c->s_outoff.p, n_off * 8, hipMemcpyDeviceToHost, s));
+    if (with_tokens && total) HIPCHK(c, hipMemcpyAsync(out_tok, c->s_out.p, total * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return L3_OK;
+}
+
+int l3_encode_batch(l3_ctx* c, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                    int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok) {
+    if (!c) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (bad_flags(c, flags)) return L3_E_INVALID_ARG;
+    if (!doc_off || !out_off || !n_tok || (!out_tok && out_cap)) { c->err = "null pointer argument"; return L3_E_INVALID_ARG; }
+    int rc = check_offsets_host(c, doc_off, n_docs);
+    if (rc) return rc;
+    const uint64_t n_bytes = doc_off[n_docs];
+    if (!text && n_bytes) { c->err = "null text"; return L3_E_INVALID_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n_bytes >= (16ull << 20) && n_docs >= 16 && is_pinned(text) && is_pinned(out_tok))   // (pageable copies do not overlap)
+        return encode_batch_pieces(c, text, doc_off, n_docs, flags, out_tok, out_cap, out_off, n_tok);
+    uint64_t total = 0;
+    rc = host_stage_encode(c, text, doc_off, n_docs, flags, &total);
     if (rc) return rc;
     *n_tok = total;
-    HIPCHK(c, hipMemcpyAsync(out_off, c->s_outoff.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
-    if (total > out_cap) {
-        HIPCHK(c, hipStreamSynchronize(s));
-        c->err = "output buffer too small";
-        return L3_E_OUTPUT_CAP;
-    }
-    if (total) HIPCHK(c, hipMemcpyAsync(out_tok, c->s_out.p, total * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    rc = host_stage_download(c, n_docs + 1, total, total <= out_cap, out_tok, out_off);
+    if (rc) return rc;
+    if (total > out_cap) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
     return L3_OK;
 }
 
@@ -1044,6 +1062,132 @@ int l3_last_counters(l3_ctx* c, uint64_t* out, int cap) {
     int n = cap < 8 ? cap : 8;
     for (int i = 0; i < n; i++) out[i] = c->counters[i];
     return n;
+}
+
+// ---- several GPUs behind one handle ---------------------------------------------------------------------------------
+// Documents are independent, so a batch is cut into one contiguous range of documents per context, balanced by bytes
+// (the rule of tokenizer_amd/shard.py:10-21), every range is encoded on its own GPU by a host thread of its own, and the
+// results are concatenated in range order.  Nothing crosses GPUs on the data path.
+
+struct l3_multi {
+    std::vector<l3_ctx*> ctx;
+    std::mutex mu;   // one batch at a time per handle
+    std::string err;
+};
+
+int l3_partition_by_bytes(const uint64_t* doc_off, uint64_t n_docs, int world, uint64_t* cuts) {
+    if (!doc_off || !cuts || world < 1) return L3_E_INVALID_ARG;
+    const uint64_t total = doc_off[n_docs];
+    cuts[0] = 0;
+    for (int r = 1; r < world; r++) {
+        const uint64_t target = (uint64_t)((unsigned __int128)total * (unsigned)r / (unsigned)world);
+        uint64_t lo = 0, hi = n_docs + 1;   // first index with doc_off[i] >= target
+        while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (doc_off[mid] < target) lo = mid + 1; else hi = mid; }
+        if (lo < cuts[r - 1]) lo = cuts[r - 1];
+        cuts[r] = lo < n_docs ? lo : n_docs;
+    }
+    cuts[world] = n_docs;
+    return L3_OK;
+}
+
+int l3_multi_create(const void* vocab_b64, size_t vocab_len, const void* merges_b64, size_t merges_len,
+                    const char* const* special_tokens, size_t n_special, const int* devices, int n_dev, l3_multi** out) {
+    if (!out) return L3_E_INVALID_ARG;
+    *out = nullptr;
+    if (!devices || n_dev < 1 || n_dev > 64) { g_create_err = "l3_multi_create: 1 to 64 devices"; return L3_E_INVALID_ARG; }
+    std::unique_ptr<l3_multi> m(new l3_multi());
+    for (int i = 0; i < n_dev; i++) {
+        l3_ctx* c = nullptr;
+        int rc = l3_create_ex(vocab_b64, vocab_len, merges_b64, merges_len, special_tokens, n_special, devices[i], &c);
+        if (rc != L3_OK) {
+            for (l3_ctx* x : m->ctx) l3_destroy(x);
+            return rc;
+        }
+        m->ctx.push_back(c);
+    }
+    *out = m.release();
+    return L3_OK;
+}
+
+void l3_multi_destroy(l3_multi* m) {
+    if (!m) return;
+    for (l3_ctx* c : m->ctx) l3_destroy(c);
+    delete m;
+}
+
+int l3_multi_size(const l3_multi* m) { return m ? (int)m->ctx.size() : L3_E_INVALID_ARG; }
+l3_ctx* l3_multi_context(l3_multi* m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[(size_t)i] : nullptr; }
+const char* l3_multi_last_error(const l3_multi* m) { return m ? m->err.c_str() : g_create_err.c_str(); }
+
+int l3_multi_encode_batch(l3_multi* m, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                          int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok) {
+    if (!m) return L3_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!doc_off || !out_off || !n_tok || (!out_tok && out_cap)) { m->err = "null pointer argument"; return L3_E_INVALID_ARG; }
+    l3_ctx* c0 = m->ctx[0];
+    {
+        std::lock_guard<std::mutex> l0(c0->mu);
+        if (bad_flags(c0, flags)) { m->err = c0->err; return L3_E_INVALID_ARG; }
+        int rc = check_offsets_host(c0, doc_off, n_docs);
+        if (rc) { m->err = c0->err; return rc; }
+    }
+    if (!text && doc_off[n_docs]) { m->err = "null text"; return L3_E_INVALID_ARG; }
+    const int world = (int)m->ctx.size();
+    std::vector<uint64_t> cuts((size_t)world + 1);
+    l3_partition_by_bytes(doc_off, n_docs, world, cuts.data());
+
+    // every shard: encode, meet the others (all totals known -> every base known), download to the final place
+    std::vector<uint64_t> totals((size_t)world, 0);
+    std::vector<int> rcs((size_t)world, L3_OK);
+    std::mutex meet_mu;
+    std::condition_variable meet_cv;
+    int arrived = 0;
+    bool fits = false;
+    auto shard = [&](int r) {
+        l3_ctx* c = m->ctx[(size_t)r];
+        const uint64_t d0 = cuts[(size_t)r], d1 = cuts[(size_t)r + 1], nd = d1 - d0, b0 = doc_off[d0];
+        std::lock_guard<std::mutex> lc(c->mu);
+        int rc = L3_OK;
+        std::vector<uint64_t> rel((size_t)nd + 1);
+        for (uint64_t d = 0; d <= nd; d++) rel[(size_t)d] = doc_off[d0 + d] - b0;
+        if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; rc = L3_E_HIP; }
+        if (rc == L3_OK && nd) rc = host_stage_encode(c, text + b0, rel.data(), nd, flags, &totals[(size_t)r]);
+        rcs[(size_t)r] = rc;
+        uint64_t base = 0;
+        {
+            std::unique_lock<std::mutex> lm(meet_mu);
+            if (++arrived == world) {
+                uint64_t sum = 0;
+                bool ok = true;
+                for (int i = 0; i < world; i++) { sum += totals[(size_t)i]; ok = ok && rcs[(size_t)i] == L3_OK; }
+                fits = ok && sum <= out_cap;
+                meet_cv.notify_all();
+            } else {
+                meet_cv.wait(lm, [&] { return arrived == world; });
+            }
+            for (int i = 0; i < r; i++) base += totals[(size_t)i];
+        }
+        if (rc != L3_OK || !nd) return;
+        bool all_ok = true;
+        for (int i = 0; i < world; i++) all_ok = all_ok && rcs[(size_t)i] == L3_OK;
+        if (!all_ok) return;
+        rc = host_stage_download(c, nd, totals[(size_t)r], fits, out_tok + base, out_off + d0);
+        rcs[(size_t)r] = rc;
+        if (rc == L3_OK && base) for (uint64_t d = d0; d < d1; d++) out_off[d] += base;
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < world; r++) th.emplace_back(shard, r);
+    shard(0);
+    for (std::thread& t : th) t.join();
+    uint64_t sum = 0;
+    for (int r = 0; r < world; r++) {
+        if (rcs[(size_t)r] != L3_OK) { m->err = "device " + std::to_string(m->ctx[(size_t)r]->device) + ": " + m->ctx[(size_t)r]->err; return rcs[(size_t)r]; }
+        sum += totals[(size_t)r];
+    }
+    out_off[n_docs] = sum;
+    *n_tok = sum;
+    if (sum > out_cap) { m->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
+    return L3_OK;
 }
 
 }  // extern "C"
