@@ -1,0 +1,149 @@
+"""A second, independent opinion on the oracle (SURVEY 7 step 1, 8c last paragraph): a Hugging Face `tokenizers`
+pipeline -- BPE(vocab, merges, ignore_merges=True) + Split(the published Llama-3 regex) + ByteLevel(use_regex=False) --
+built from THIS repository's data files only (no hub, no from_pretrained), compared with oracle/l3_oracle.c.
+
+It is not the reference: the reference deviates from the published regex in the ways SURVEY Appendix E lists, and the
+oracle must deviate with it.  So the test is two-sided: every input OUTSIDE the App. E classes must agree id for id, and
+the App. E examples must disagree in exactly the documented way.  What this buys: the oracle and the HIP tables share one
+generated Unicode table (unicode15_ranges.h) and one reading of the data files; `tokenizers` shares neither.
+
+Container-only: skipped where `tokenizers` is not importable; nothing here runs on the GPU."""
+import base64
+import json
+import os
+import random
+import re
+import unicodedata
+
+import numpy as np
+import pytest
+
+tokenizers = pytest.importorskip("tokenizers")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "tokenizer_amd", "data")
+GOLD = os.path.join(ROOT, "tests", "golden")
+LLAMA3_REGEX = (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|"
+                r"\s+(?!\S)|\s+")   # llama3/IMPLEMENTATION.md:42-45
+
+
+@pytest.fixture(scope="module")
+def hf():
+    from tokenizers import Regex, Tokenizer, decoders, models, pre_tokenizers
+    vraw = base64.b64decode(open(os.path.join(DATA, "vocab_base64.txt"), "rb").read()).decode("utf-8")
+    toks = [t for t in vraw.split("\n") if t]
+    mraw = base64.b64decode(open(os.path.join(DATA, "merges_binary.txt"), "rb").read())
+    bits = np.unpackbits(np.frombuffer(mraw, dtype=np.uint8))
+    n_ids = bits.size // 17
+    ids = bits[:n_ids * 17].reshape(n_ids, 17).astype(np.int64) @ (1 << np.arange(16, -1, -1)).astype(np.int64)
+    merges = [(toks[int(ids[k])], toks[int(ids[k + 1])]) for k in range(0, n_ids - 1, 2)]
+    tk = Tokenizer(models.BPE(vocab={t: i for i, t in enumerate(toks)}, merges=merges, ignore_merges=True))
+    tk.pre_tokenizer = pre_tokenizers.Sequence([
+        pre_tokenizers.Split(Regex(LLAMA3_REGEX), behavior="isolated", invert=False),
+        pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    tk.decoder = decoders.ByteLevel()
+    assert len(toks) == 128000
+    return tk
+
+
+def _in_appendix_e(s: str) -> bool:
+    """Could the reference legitimately differ from the published regex on s?  """
+    for ch in s:
+        cat = unicodedata.category(ch)
+        if cat in ("No", "Nl"):                      # 1: \p{N} is Nd only in the reference
+            return True
+        if ch in "ſK":                      # 3: (?i) folds these onto s / k, the reference does not
+            return True
+        if ch in "\x1c\x1d\x1e\x1f\x85﻿":        # 5: corners of \s on which regex engines differ
+            return True
+        if cat == "Cn":                              # unknown to python's Unicode tables: class cannot be argued here
+            return True
+    # 2: \s*[\r\n]+ does not backtrack: a newline, then blanks that are not newlines, then another newline
+    return re.search(r"[\r\n][^\S\r\n]+[\r\n]", s) is not None
+
+
+def _inputs():
+    """A corpus in the spirit of internal/testing/vectors.go:18-252 (whitespace runs, contractions in every case, digit
+    runs, punctuation, scripts, mixed lines) plus every input string of the committed reference fixtures."""
+    out = ["", " ", "\t", "\n", "\r\n", "'", "''", "123456"]
+    for i in range(1, 21):
+        out += [" " * i + "word", "word" + " " * i, " " * i + "\n" + "x", "a" + " " * i + "b"]
+    for i in range(1, 11):
+        out += ["\t" * i + "word", "\n" * i + "word", "word" + "\n" * i, "\r\n" * i]
+    out += [" \t \t word", "\n\r\n\r\nword", "   \t\t\t   \n\n\n   word", "word   \t\t\t   \n\n\n", "a b", "a　b c"]
+    for w in ["can", "won", "they", "I", "we", "he", "it", "été", "你"]:
+        for c in ["'s", "'t", "'re", "'ve", "'m", "'ll", "'d", "'x", "'", "'ree", "'lll"]:
+            out += [w + c, w.upper() + c, w + c.upper(), w.capitalize() + c, w + c + " next", w + " " + c]
+    out += ["0", "00", "000", "0000", "123", "1234", "12345", "1 2 3", "12 34 56", "123 456 789", "1234567890" * 3, "a1b22c333d4444",
+            "٠١٢٣", "१२३४५", "3.14159", "1,000,000", "x1", "1x", " 1", "1 ", "\n1"]
+    punct = "!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~"
+    out += list(punct) + [p * 3 for p in punct] + [" " + p for p in punct] + [p + "\n" for p in punct] + [p + "a" for p in punct]
+    out += ["!!!\n\n", "...\r\n", "a.b", "a, b", "(a)", "[1]", "{x}", "a-b", "a_b", "a/b", "#tag", "@user", "$100", "50%", "C++", "a&&b"]
+    out += ["Hello world!", "Hello, World! How are you?", "The quick brown fox jumps over the lazy dog.",
+            "def f(x):\n    return x + 1\n", "int main() {\n\tprintf(\"hi\\n\");\n}\n", "SELECT * FROM t WHERE a = 'b';",
+            "https://example.com/path?q=1&r=2", "user@example.com", "snake_case camelCase PascalCase kebab-case",
+            "Ünïcödé", "naïve café résumé", "Привет, мир!", "Γειά σου Κόσμε", "שלום עולם", "مرحبا بالعالم", "नमस्ते दुनिया",
+            "こんにちは世界", "안녕하세요 세계", "你好，世界！", "ไทย ภาษา", "🦙 llama", "👨‍👩‍👧‍👦 family", "áè", "🇺🇸🇯🇵", "ＡＢＣ　１２３",
+            "<|begin_of_text|>", "<|not_special|>", "<|", "|>", "<|eot_id|", "text<|end_of_text|>more"]
+    rng = random.Random(1)
+    alphabet = ["a", "b", "Z", " ", " ", "  ", "\n", "\t", "1", "23", "'s", "'T", ".", ",", "!", "é", "ß", "你", "好", "🦙", "-", "_", "\r\n", "x" * 9]
+    for _ in range(150):
+        out.append("".join(rng.choice(alphabet) for _ in range(rng.randrange(1, 40))))
+    for name in ("ref_encode_kats.json", "ref_pretokenize_kats.json", "ref_comparison_inputs.json"):
+        d = json.load(open(os.path.join(GOLD, name), encoding="utf-8"))
+        stack = [d]
+        while stack:
+            x = stack.pop()
+            if isinstance(x, dict):
+                stack += [v for k, v in x.items() if k in ("encode", "cases", "inputs", "input", "text", "large")] + \
+                         [v for k, v in x.items() if isinstance(v, (dict, list))]
+            elif isinstance(x, list):
+                stack += x
+            elif isinstance(x, str):
+                out.append(x)
+    seen, uniq = set(), []
+    for s in out:
+        if s not in seen:
+            seen.add(s)
+            uniq.append(s)
+    return uniq
+
+
+def test_hf_pipeline_agrees_outside_appendix_e(hf, oracle):
+    inputs = _inputs()
+    assert len(inputs) >= 536
+    checked = excluded = 0
+    for s in inputs:
+        try:
+            raw = s.encode("utf-8")
+        except UnicodeEncodeError:       # lone surrogates from a fixture: not a Go string either
+            continue
+        if "<|" in s and "|>" in s:      # special tokens are the reference's own layer (special.go), not the HF pipeline's
+            continue
+        want = hf.encode(s, add_special_tokens=False).ids
+        got = oracle.encode(raw, False, False)
+        if _in_appendix_e(s):
+            excluded += 1
+            continue
+        assert got == want, (s, got, want)
+        checked += 1
+    assert checked >= 500 and excluded < checked // 10, (checked, excluded)
+
+
+def test_appendix_e_examples_differ_as_documented(hf, oracle):
+    # reference ids vs regex-exact ids
+    cases = [
+        ("x² ½ Ⅷ ①", [87, 30556, 2188, 121, 2928, 92871, 2928, 239, 254], [87, 30556, 220, 27154, 220, 71567, 100, 220, 118075]),
+        ("\n \n", [198, 720], [27907]),
+        ("  \n  \n x", [2355, 2355, 865], [31879, 865]),
+    ]
+    for s, ref_ids, regex_ids in cases:
+        assert _in_appendix_e(s)
+        assert oracle.encode(s.encode(), False, False) == ref_ids
+        assert hf.encode(s, add_special_tokens=False).ids == regex_ids
+
+
+def test_hf_decode_round_trip_matches_oracle_decode(hf, oracle):
+    for s in ["Hello world!", "naïve café 你好 🦙", "  leading and trailing  ", "tabs\tand\nnewlines\r\n"]:
+        ids = oracle.encode(s.encode(), False, False)
+        assert hf.decode(ids, skip_special_tokens=False) == oracle.decode(ids).decode("utf-8") == s
