@@ -126,7 +126,8 @@ int l3_host_free(l3_ctx* ctx, void* p);
 /* Measurement support (no counterpart in the reference): when enabled, HIP events are recorded on the
  * launch stream between the kernels of every encode call; l3_last_timings() returns the milliseconds of
  * the last call: [0] validate+docs, [1] tile kernel, [2] merge kernel, [3] slow kernel, [4] scan, [5] emit,
- * [6] first kernel start -> last kernel end.  Returns the number of values written.  enabled = 2: only the events the
+ * [6] first kernel start -> last kernel end, [7] (cap >= 8) the kernels of the last l3_decode_batch.  Returns the number of
+ * values written.  enabled = 2: only the events the
  * roofline figures need (around the tile kernel, and first start / last end): [0], [1] and [6] are filled in, the others 0;
  * every event between two kernels keeps the second from starting early, four of them cost a 64 MiB batch about 3 %. */
 int l3_set_profiling(l3_ctx* ctx, int enabled);

@@ -175,7 +175,10 @@ long long l3h_streams(void* h, const uint8_t* data, const long long* off, int n_
     if (buf_size > 0) o.bufSize = buf_size;
     o.enc.BOS = bos != 0; o.enc.EOS = eos != 0;
     std::vector<std::vector<int>> res;
-    if (EncodeStreams(*(Tokenizer*)h, ps, o, &res)) return -1;
+    if (Error e = EncodeStreams(*(Tokenizer*)h, ps, o, &res)) {
+        fprintf(stderr, "l3h_streams: %s\n", e.Message().c_str());
+        return -1;
+    }
     long long k = 0;
     out_off[0] = 0;
     for (int i = 0; i < n_streams; i++) {

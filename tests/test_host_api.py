@@ -347,7 +347,14 @@ def test_with_devices_shards_streams(tok, oracle):
         rng = random.Random(11)
         words = ["alpha", "beta", " ", "\n", "世界", "1234567", "don't", "<|eot_id|>"]
         streams = ["".join(rng.choice(words) for _ in range(rng.randrange(1, 600))).encode() for _ in range(30)]
-        assert t.streams(streams, buf_size=256, opts=(True, True)) == tok.streams(streams, buf_size=256, opts=(True, True))
+        got = t.streams(streams, buf_size=256, opts=(True, True))
+        for i, s in enumerate(streams):
+            want = _expected_scan(oracle, s, (), 256, 1 << 20, (True, True))
+            if got[i] != want:
+                k = next((j for j in range(min(len(got[i]), len(want))) if got[i][j] != want[j]), min(len(got[i]), len(want)))
+                raise AssertionError("stream %d: %d ids, want %d; first difference at %d: %r != %r; single context right: %r" % (
+                    i, len(got[i]), len(want), k, got[i][max(0, k - 4):k + 12], want[max(0, k - 4):k + 12],
+                    tok.streams([s], buf_size=256, opts=(True, True))[0] == want))
         assert t.encode(b"Hello world!") == oracle.encode(b"Hello world!", True, True)
         assert t.decode([9906, 1917, 0]) == b"Hello world!" and t.vocab_size() == 128256
     finally:

@@ -261,9 +261,9 @@ class Context:
         self.lib.l3_set_profiling(self.h, int(on))
 
     def last_timings(self):
-        a = np.zeros(7, dtype=np.float32)
-        self.lib.l3_last_timings(self.h, a.ctypes.data, 7)
-        return dict(zip(["docs", "tile", "merge", "slow", "scan", "emit", "total"], a.tolist()))
+        a = np.zeros(8, dtype=np.float32)
+        self.lib.l3_last_timings(self.h, a.ctypes.data, 8)
+        return dict(zip(["docs", "tile", "merge", "slow", "scan", "emit", "total", "decode"], a.tolist()))
 
     def timing_totals(self):
         """(sums of the seven timings over the profiled calls since set_profiling, number of those calls)"""

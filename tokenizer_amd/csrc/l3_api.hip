@@ -83,13 +83,16 @@ struct l3_ctx {
     // every batch: the caller's stream handle is never kept, it may be destroyed between two calls.
     uint32_t slow_grid = 32;          // slow_kernel's grid for the next batch: all of it once a batch had window items, a few
                                       // workgroups (an empty launch costs 8 us otherwise) while batches have none
-    bool status_dirty = false;        // a call ended (with an error) between two host-driven passes: the word is zeroed first
+    bool status_dirty = false;        // the word must be zeroed in front of the next batch: it is new, or a call ended (with an
+                                      // error) between two host-driven passes
     bool order_pending = false;       // ev_order has been recorded behind the last batch
     bool order_on_own = false;        // ... on the context's own stream (same-stream order makes the wait unnecessary)
     hipEvent_t ev_order = nullptr;
     DevBuf w_arena, w_status;         // the per-call workspace (one block, carve_workspace) and the status word
     DevBuf w_giant;                   // flat arrays of the grid-wide merge of giant pieces (only batches that have such pieces)
-    DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total;
+    DevBuf s_text, s_off, s_out, s_outoff, s_kinds, s_ids, s_idoff, s_total, s_decblk;
+    hipEvent_t ev_dec[2] = {};          // around the decode kernels when profiling is on
+    float last_decode_ms = 0.f;
     Caps caps{0, 0, 0, 0, 0, 0};         // list capacities inside the workspace, grow-only
     unsigned char* na_scratch = nullptr;  // this GPU's copy of the file-scope array `scratch` (hipGetSymbolAddress at l3_create)
     Status* h_status = nullptr;          // pinned
@@ -169,6 +172,8 @@ int upload_tables(l3_ctx* c) {
     T.pair_log2 = H.pair_log2;
     T.vocab_log2 = H.vocab_log2;
     T.bloom_log2 = H.bloom_log2;
+    // the copies above went through the null stream; the context's stream is non-blocking and does not wait for it
+    HIPCHK(c, hipDeviceSynchronize());
     return L3_OK;
 }
 
@@ -235,8 +240,11 @@ bool caps_addressable(const Caps& K) {
 
 int ensure_workspace(l3_ctx* c, uint64_t n_bytes, uint64_t n_docs, Workspace& W) {
     if (!c->w_status.p) {
+        // Cleared in stream order in front of the first batch (status_dirty).  NOT with hipMemset here: that runs on the null
+        // stream, which the context's non-blocking stream does not wait for -- the first batch of a new context could start
+        // on whatever the recycled memory held, or have its flags wiped under it.
         HIPCHK(c, c->w_status.ensure(sizeof(Status)));
-        HIPCHK(c, hipMemset(c->w_status.p, 0, sizeof(Status)));
+        c->status_dirty = true;
     }
     const Caps K0 = initial_caps(n_bytes);
     Caps& K = c->caps;   // grow-only across calls
@@ -353,8 +361,8 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         Workspace W{};
         int rc = ensure_workspace(c, A.n_bytes, A.n_docs, W);
         if (rc) return rc;
-        // W.status is all zero here: cleared when the context made it and again after every read-back below, so the
-        // clear runs while the host is busy between two calls instead of in front of the kernels
+        // W.status is all zero here (or status_dirty says otherwise): cleared after every read-back below, so the clear
+        // runs while the host is busy between two calls instead of in front of the kernels
         if ((rc = order_behind_last(c, stream))) return rc;
         if (c->status_dirty) { HIPCHK(c, hipMemsetAsync(W.status, 0, sizeof(Status), stream)); c->status_dirty = false; }
         HIPCHK(c, launch_encode(c->T, W, A, stream, c->profiling ? c->ev : nullptr, false, c->profiling_light ? kEvLight : kEvAll));
@@ -527,8 +535,9 @@ void l3_destroy(l3_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
                       &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->t_prefix2, &c->t_bloom, &c->w_arena, &c->w_status, &c->w_giant, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
-                      &c->s_total};
+                      &c->s_total, &c->s_decblk};
     for (DevBuf* b : bufs) b->release();
+    for (int i = 0; i < 2; i++) if (c->ev_dec[i]) (void)hipEventDestroy(c->ev_dec[i]);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->have_events)
@@ -967,17 +976,23 @@ int l3_decode_batch(l3_ctx* c, const int32_t* ids, const uint64_t* id_off, uint6
     HIPCHK(c, c->s_idoff.ensure((n_seqs + 1) * 8));
     HIPCHK(c, c->s_outoff.ensure((n_seqs + 1) * 8));
     HIPCHK(c, c->s_total.ensure(16));
+    HIPCHK(c, c->s_decblk.ensure((decode_blocks(n_ids) + 1) * 8));
+    if (c->profiling && !c->ev_dec[0]) for (int i = 0; i < 2; i++) HIPCHK(c, hipEventCreate(&c->ev_dec[i]));
     // every id decodes to at most kMaxTokenBytes bytes; start from a typical size and retry once
     uint64_t guess = n_ids * 6 + 1024;
     HIPCHK(c, c->s_kinds.ensure(guess));
     if (n_ids) HIPCHK(c, hipMemcpyAsync(c->s_ids.p, ids, n_ids * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->s_idoff.p, id_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, s));
     for (int attempt = 0; attempt < 2; attempt++) {
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_dec[0], s));
         HIPCHK(c, launch_decode(c->t_tokoff.as<uint32_t>(), c->t_tokbytes.as<uint8_t>(), c->H.n_tokens,
-                                c->s_ids.as<int32_t>(), c->s_idoff.as<uint64_t>(), n_seqs, c->s_kinds.as<uint8_t>(),
-                                c->s_kinds.cap, c->s_outoff.as<uint64_t>(), c->s_total.as<unsigned long long>(), s));
+                                c->s_ids.as<int32_t>(), n_ids, c->s_idoff.as<uint64_t>(), n_seqs, c->s_decblk.as<uint64_t>(),
+                                c->s_kinds.as<uint8_t>(), c->s_kinds.cap, c->s_outoff.as<uint64_t>(),
+                                c->s_total.as<unsigned long long>(), s));
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_dec[1], s));
         HIPCHK(c, hipMemcpyAsync(c->h_total, c->s_total.p, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->last_decode_ms, c->ev_dec[0], c->ev_dec[1]));
         if (*c->h_total <= c->s_kinds.cap) break;
         HIPCHK(c, c->s_kinds.ensure(*c->h_total));
     }
@@ -1044,6 +1059,7 @@ int l3_last_timings(l3_ctx* c, float* ms, int cap) {
     std::lock_guard<std::mutex> lk(c->mu);
     int n = cap < kEvCount ? cap : kEvCount;
     for (int i = 0; i < n; i++) ms[i] = c->last_ms[i];
+    if (cap > kEvCount) ms[n++] = c->last_decode_ms;
     return n;
 }
 

@@ -215,9 +215,11 @@ hipError_t launch_giants_rounds(const Tables& T, const Workspace& W, uint64_t n_
 hipError_t launch_giants_store(const Workspace& W, uint64_t n_syms, void* flat, hipStream_t stream);
 // The second half of the final scatter, for the tiles the fast emit kernel flagged (Status::generic_tiles > 0).
 hipError_t launch_emit_generic(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
-// Decode: ids -> bytes (tokenizer.go:339-354).  Two passes: lengths+scan, then copy.
-hipError_t launch_decode(const uint32_t* tok_off, const uint8_t* tok_bytes, int n_tokens, const int32_t* ids,
-                         const uint64_t* id_off, uint64_t n_seqs, uint8_t* out, uint64_t out_cap,
+// Decode: ids -> bytes (tokenizer.go:339-354) in blocks of ids, whatever the sequences are: block sums, their scan, then the
+// bytes and the sequence offsets.  block_base: decode_blocks(n_ids) + 1 words of workspace.
+uint64_t decode_blocks(uint64_t n_ids);
+hipError_t launch_decode(const uint32_t* tok_off, const uint8_t* tok_bytes, int n_tokens, const int32_t* ids, uint64_t n_ids,
+                         const uint64_t* id_off, uint64_t n_seqs, uint64_t* block_base, uint8_t* out, uint64_t out_cap,
                          uint64_t* out_off, unsigned long long* total, hipStream_t stream);
 
 }  // namespace l3
