@@ -16,6 +16,8 @@
 //                                             llama3/scanner/scanner.go:12-111,241-333 (chunking rules :124-181,337-478)
 //   Tokenizer::NewScanner / Process           llama3/scanner.go:67-102 (Process writes uint32 little-endian)
 //   Tokenizer::TokenStream                    llama3/scanner.go:107-132 (a bounded channel of 100 fed by a thread)
+//   WithDataLoader / VocabularyDataLoader     options.go:52-60, vocab.go:14-22 (tokens + merge map from any source; the shim
+//                                             packs them into the two file formats the C ABI takes)
 //   WithSpecialTokens                         options.go:17-37 (the list replaces the 256 defaults; ConfigError on a
 //                                             malformed or duplicated name)
 //   EncodeStreams                             new, additive: many streams, the scanner's chunks, ONE batch call
@@ -25,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -32,6 +35,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "l3hip.h"
@@ -52,8 +56,18 @@ struct EncodeOptions {  // tokenizer.go:107-112
     bool EOS = true;
 };
 
+// llama3/vocab.go:14-22: a source of vocabulary data.  LoadVocabulary: the token strings in id order, in the byte-level
+// alphabet the reference's vocabulary file uses (internal/encoding/encoding.go:26-79).  LoadMerges: merge identifier
+// "left right" (tokenizer.go:425-427) -> priority, smaller = earlier.  Either returns false (and may fill *err) on failure.
+struct VocabularyDataLoader {
+    virtual bool LoadVocabulary(std::vector<std::string>* tokens, Error* err) = 0;
+    virtual bool LoadMerges(std::unordered_map<std::string, int>* merges, Error* err) = 0;
+    virtual ~VocabularyDataLoader() {}
+};
+
 // ---- options (llama3/options.go) ----------------------------------------------------------------------
 struct Config {
+    VocabularyDataLoader* dataLoader = nullptr;  // WithDataLoader (not owned; used inside New only)
     std::string vocabPath, mergesPath;  // WithDataFiles
     int device = 0;                     // new: which GPU holds the tables
     std::vector<int> devices;           // new: WithDevices -- batches are sharded over these GPUs
@@ -68,9 +82,16 @@ struct Option {
     int which = 0;
     std::vector<std::string> list;
     std::vector<int> ints;
+    VocabularyDataLoader* loader = nullptr;
     void Apply(Config& c) const {
         if (which == 4) c.devices = ints;
-        if (which == 1) { c.vocabPath = a; c.mergesPath = b; }
+        if (which == 5) {  // options.go:52-60
+            if (!loader) { c.err.kind = ErrKind::Config; c.err.op = "data_loader"; c.err.detail = "nil"; return; }
+            c.dataLoader = loader;
+            c.vocabPath.clear();
+            c.mergesPath.clear();
+        }
+        if (which == 1) { c.vocabPath = a; c.mergesPath = b; c.dataLoader = nullptr; }  // (the last data option wins, as in Go)
         if (which == 2) c.device = i;
         if (which == 3) {  // options.go:19-33: each name is <|...|> of at least 5 bytes, and none appears twice
             for (size_t k = 0; k < list.size(); k++) {
@@ -94,6 +115,8 @@ inline Option WithDataFiles(const std::string& vocabPath, const std::string& mer
     Option o; o.which = 1; o.a = vocabPath; o.b = mergesPath; return o;
 }
 inline Option WithDevice(int device) { Option o; o.which = 2; o.i = device; return o; }
+// options.go:52-60: vocabulary and merges from a caller-supplied source.  The loader is called inside New() and not kept.
+inline Option WithDataLoader(VocabularyDataLoader* loader) { Option o; o.which = 5; o.loader = loader; return o; }
 // One context per entry; EncodeBatch (and everything built on it) cuts a batch into byte-balanced ranges of documents, one per
 // GPU.  Single-document calls and Decode use the first device.
 inline Option WithDevices(const std::vector<int>& devices) { Option o; o.which = 4; o.ints = devices; return o; }
@@ -594,6 +617,78 @@ inline bool ReadFile(const std::string& path, std::string* out) {
     return true;
 }
 
+inline std::string Base64(const std::string& in) {
+    static const char* A = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    std::string out;
+    out.reserve((in.size() + 2) / 3 * 4);
+    for (size_t i = 0; i < in.size(); i += 3) {
+        const uint32_t n = (size_t)(in.size() - i) >= 3 ? 3u : (uint32_t)(in.size() - i);
+        uint32_t v = (uint32_t)(uint8_t)in[i] << 16;
+        if (n > 1) v |= (uint32_t)(uint8_t)in[i + 1] << 8;
+        if (n > 2) v |= (uint32_t)(uint8_t)in[i + 2];
+        out += A[(v >> 18) & 63]; out += A[(v >> 12) & 63];
+        out += n > 1 ? A[(v >> 6) & 63] : '=';
+        out += n > 2 ? A[v & 63] : '=';
+    }
+    return out;
+}
+
+// What a VocabularyDataLoader returns, packed into the reference's two file formats: the vocabulary file is
+// base64 of the '\n'-separated token strings in id order (decoder.go:16-36); the merges file is base64 of the pairs
+// (idA, idB) in priority order, 17 bits per id, most significant bit first (decoder.go:41-126).  Priorities only matter
+// through their order (bpe.go:126: rank + position / length), so the map's values need not be 1, 2, 3, ...; two rules of
+// EQUAL priority cannot be expressed in the file format and are refused.
+inline bool PackLoaderData(VocabularyDataLoader* loader, std::string* vocab_b64, std::string* merges_b64, Error* err) {
+    auto fail = [&](ErrKind k, const char* op, const std::string& detail) {
+        if (err && !*err) { err->kind = k; err->op = op; err->detail = detail; }
+        return false;
+    };
+    std::vector<std::string> tokens;
+    if (!loader->LoadVocabulary(&tokens, err)) return fail(ErrKind::DataNotFound, "load vocabulary", "loader failed");
+    if (tokens.size() >= (1u << 17)) return fail(ErrKind::DataNotFound, "load vocabulary", "more than 131,071 tokens");
+    std::string lines;
+    std::unordered_map<std::string, int> lookup;   // tokenizer.go:201-204: later ids overwrite earlier ones
+    for (size_t i = 0; i < tokens.size(); i++) {
+        if (tokens[i].empty() || tokens[i].find('\n') != std::string::npos)
+            return fail(ErrKind::DataNotFound, "load vocabulary", "empty token or newline in token " + std::to_string(i));
+        lines += tokens[i];
+        lines += '\n';
+        lookup[tokens[i]] = (int)i;
+    }
+    std::unordered_map<std::string, int> merges;
+    if (!loader->LoadMerges(&merges, err)) return fail(ErrKind::DataNotFound, "load merges", "loader failed");
+    std::vector<std::pair<int, const std::string*>> order;
+    order.reserve(merges.size());
+    for (const auto& kv : merges) order.push_back({kv.second, &kv.first});
+    std::sort(order.begin(), order.end(), [](const std::pair<int, const std::string*>& a, const std::pair<int, const std::string*>& b) {
+        return a.first != b.first ? a.first < b.first : *a.second < *b.second;
+    });
+    std::string bits;   // packed ids
+    uint64_t acc = 0;
+    int n_acc = 0;
+    auto put17 = [&](uint32_t id) {
+        acc = (acc << 17) | id;
+        n_acc += 17;
+        while (n_acc >= 8) { bits += (char)((acc >> (n_acc - 8)) & 0xFF); n_acc -= 8; }
+    };
+    for (size_t k = 0; k < order.size(); k++) {
+        if (k && order[k].first == order[k - 1].first)
+            return fail(ErrKind::DataNotFound, "load merges", "two merge rules share priority " + std::to_string(order[k].first));
+        const std::string& key = *order[k].second;
+        const size_t sp = key.find(' ');   // byte-level token strings hold no ' ' (the space byte is U+0120)
+        if (sp == std::string::npos || key.find(' ', sp + 1) != std::string::npos)
+            return fail(ErrKind::DataNotFound, "load merges", "merge identifier is not \"left right\": " + key);
+        auto a = lookup.find(key.substr(0, sp)), b = lookup.find(key.substr(sp + 1));
+        if (a == lookup.end() || b == lookup.end()) continue;   // names no token: such a rule can never apply
+        put17((uint32_t)a->second);
+        put17((uint32_t)b->second);
+    }
+    if (n_acc) bits += (char)((acc << (8 - n_acc)) & 0xFF);   // zero bits pad the last byte
+    *vocab_b64 = Base64(lines);
+    *merges_b64 = Base64(bits);
+    return true;
+}
+
 // New (tokenizer.go:142-213).  The Go package embeds the two data files; a C++ build names them with
 // WithDataFiles (options.go) or the L3_DATA_DIR environment variable.
 inline std::unique_ptr<Tokenizer> New(const std::vector<Option>& opts, Error* err) {
@@ -602,16 +697,21 @@ inline std::unique_ptr<Tokenizer> New(const std::vector<Option>& opts, Error* er
         o.Apply(c);
         if (c.err) { if (err) *err = c.err; return nullptr; }  // tokenizer.go:151-155
     }
-    if (c.vocabPath.empty()) {
-        const char* d = getenv("L3_DATA_DIR");
-        std::string dir = d ? d : "tokenizer_amd/data";
-        c.vocabPath = dir + "/vocab_base64.txt";
-        c.mergesPath = dir + "/merges_binary.txt";
-    }
     std::string vocab, merges;
-    if (!ReadFile(c.vocabPath, &vocab) || !ReadFile(c.mergesPath, &merges)) {
-        if (err) { err->kind = ErrKind::DataNotFound; err->op = "load vocabulary"; err->detail = c.vocabPath; }
-        return nullptr;
+    if (c.dataLoader) {
+        Error le;
+        if (!PackLoaderData(c.dataLoader, &vocab, &merges, &le)) { if (err) *err = le; return nullptr; }
+    } else {
+        if (c.vocabPath.empty()) {
+            const char* d = getenv("L3_DATA_DIR");
+            std::string dir = d ? d : "tokenizer_amd/data";
+            c.vocabPath = dir + "/vocab_base64.txt";
+            c.mergesPath = dir + "/merges_binary.txt";
+        }
+        if (!ReadFile(c.vocabPath, &vocab) || !ReadFile(c.mergesPath, &merges)) {
+            if (err) { err->kind = ErrKind::DataNotFound; err->op = "load vocabulary"; err->detail = c.vocabPath; }
+            return nullptr;
+        }
     }
     std::unique_ptr<Tokenizer> t(new Tokenizer());
     int rc;

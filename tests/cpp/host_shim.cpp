@@ -27,6 +27,66 @@ struct ControlledReader : Reader {
         return (int)m;
     }
 };
+// A VocabularyDataLoader (vocab.go:14-22) over the two data files: what a caller with its own storage would write.
+// Decodes the files itself (base64, '\n'-separated tokens; 17-bit id pairs -> "left right" -> rank) so that New() sees
+// nothing but token strings and a merge map.  rank_step spreads the priorities (1, 1 + step, ...): only their order counts.
+struct FileBackedLoader : VocabularyDataLoader {
+    std::string dir;
+    int rank_step;
+    bool fail_merges;
+    std::vector<std::string> toks;
+    FileBackedLoader(const std::string& d, int step, bool fm) : dir(d), rank_step(step), fail_merges(fm) {}
+    static bool unb64(const std::string& in, std::string* out) {
+        int val[256];
+        for (int i = 0; i < 256; i++) val[i] = -1;
+        const char* A = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+        for (int i = 0; i < 64; i++) val[(unsigned char)A[i]] = i;
+        uint32_t acc = 0;
+        int n = 0;
+        for (unsigned char c : in) {
+            if (c == '=' || c == '\n' || c == '\r') continue;
+            if (val[c] < 0) return false;
+            acc = (acc << 6) | (uint32_t)val[c];
+            n += 6;
+            if (n >= 8) { out->push_back((char)((acc >> (n - 8)) & 0xFF)); n -= 8; }
+        }
+        return true;
+    }
+    bool LoadVocabulary(std::vector<std::string>* tokens, Error* err) override {
+        std::string file, raw;
+        if (!ReadFile(dir + "/vocab_base64.txt", &file) || !unb64(file, &raw)) {
+            if (err) { err->kind = ErrKind::DataNotFound; err->op = "loader"; err->detail = dir; }
+            return false;
+        }
+        size_t s = 0;
+        for (size_t i = 0; i <= raw.size(); i++)
+            if (i == raw.size() || raw[i] == '\n') { if (i > s) toks.push_back(raw.substr(s, i - s)); s = i + 1; }
+        *tokens = toks;
+        return true;
+    }
+    bool LoadMerges(std::unordered_map<std::string, int>* merges, Error* err) override {
+        std::string file, raw;
+        if (fail_merges || !ReadFile(dir + "/merges_binary.txt", &file) || !unb64(file, &raw)) {
+            if (err) { err->kind = ErrKind::DataNotFound; err->op = "loader merges"; err->detail = dir; }
+            return false;
+        }
+        std::vector<uint32_t> ids;
+        uint64_t acc = 0;
+        int n = 0;
+        for (unsigned char c : raw) {
+            acc = (acc << 8) | c;
+            n += 8;
+            if (n >= 17) { ids.push_back((uint32_t)((acc >> (n - 17)) & 0x1FFFF)); n -= 17; }
+        }
+        int rank = 1;
+        for (size_t k = 0; k + 1 < ids.size(); k += 2) {
+            if (ids[k] >= toks.size() || ids[k + 1] >= toks.size()) continue;
+            (*merges)[toks[ids[k]] + " " + toks[ids[k + 1]]] = rank;
+            rank += rank_step;
+        }
+        return true;
+    }
+};
 struct VecWriter : Writer {
     std::vector<uint8_t> v;
     bool Write(const uint8_t* p, size_t n) override { v.insert(v.end(), p, p + n); return true; }
@@ -85,6 +145,27 @@ void* l3h_new_devices(const int* devices, int n, const char* data_dir, int* err_
     std::unique_ptr<Tokenizer> t = New(opts, &e);
     if (err_kind) *err_kind = (int)e.kind;
     return t.release();
+}
+// New(WithDataLoader(loader)) with a loader over the files in data_dir; null_loader: WithDataLoader(nil)
+void* l3h_new_loader(int device, const char* data_dir, int rank_step, int fail_merges, int null_loader, int* err_kind) {
+    Error e;
+    FileBackedLoader loader(data_dir, rank_step, fail_merges != 0);
+    std::unique_ptr<Tokenizer> t = New({WithDevice(device), WithDataLoader(null_loader ? nullptr : &loader)}, &e);
+    if (err_kind) *err_kind = (int)e.kind;
+    return t.release();
+}
+// PackLoaderData on that loader (host arithmetic only): the two files it produces; returns 0, or the error kind
+int l3h_pack_loader(const char* data_dir, int rank_step, char* vocab, long long vocab_cap, long long* vocab_len, char* merges,
+                    long long merges_cap, long long* merges_len) {
+    Error e;
+    FileBackedLoader loader(data_dir, rank_step, false);
+    std::string v, m;
+    if (!PackLoaderData(&loader, &v, &m, &e)) return (int)e.kind ? (int)e.kind : -1;
+    *vocab_len = (long long)v.size();
+    *merges_len = (long long)m.size();
+    if ((long long)v.size() <= vocab_cap) memcpy(vocab, v.data(), v.size());
+    if ((long long)m.size() <= merges_cap) memcpy(merges, m.data(), m.size());
+    return 0;
 }
 void l3h_free(void* h) { delete (Tokenizer*)h; }
 

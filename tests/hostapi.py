@@ -32,6 +32,10 @@ def load():
         L.l3h_new_special.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
         L.l3h_new_devices.restype = _P
         L.l3h_new_devices.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+        L.l3h_new_loader.restype = _P
+        L.l3h_new_loader.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.l3h_pack_loader.restype = C.c_int
+        L.l3h_pack_loader.argtypes = [C.c_char_p, C.c_int, _P, _LL, C.POINTER(_LL), _P, _LL, C.POINTER(_LL)]
         L.l3h_token_stream.restype = _LL
         L.l3h_token_stream.argtypes = [_P, _P, _LL, _P, C.c_int, _LL, _P, _LL]
         L.l3h_free.argtypes = [_P]
@@ -64,6 +68,18 @@ def _sizes(read_sizes):
     return a, (a.ctypes.data if a.size else None), int(a.size)
 
 
+def pack_loader(data_dir=DATA, rank_step=1):
+    """The two data files llama3::PackLoaderData makes from a VocabularyDataLoader over the files in data_dir (no GPU)."""
+    L = load()
+    cap = 8 << 20
+    v, m = np.empty(cap, dtype=np.uint8), np.empty(cap, dtype=np.uint8)
+    vl, ml = _LL(0), _LL(0)
+    rc = L.l3h_pack_loader(data_dir.encode(), rank_step, v.ctypes.data, cap, C.byref(vl), m.ctypes.data, cap, C.byref(ml))
+    if rc != 0:
+        raise RuntimeError("PackLoaderData failed, error kind %d" % rc)
+    return v[:vl.value].tobytes(), m[:ml.value].tobytes()
+
+
 def chunks(data: bytes, read_sizes=None, buf_size=0, max_buffer=0):
     """[(chunk, scanner knew it was at EOF)] as the scanner would hand them to Encode (same shape as
     tests/scanner_model.chunks); None on a reader error."""
@@ -85,11 +101,14 @@ def chunks(data: bytes, read_sizes=None, buf_size=0, max_buffer=0):
 class Tokenizer:
     """llama3::Tokenizer (needs a GPU)."""
 
-    def __init__(self, device=0, data_dir=DATA, specials=None, devices=None):
-        """specials: list of bytes -> New(WithSpecialTokens(list)); devices: list of ints -> New(WithDevices(list))"""
+    def __init__(self, device=0, data_dir=DATA, specials=None, devices=None, loader=None):
+        """specials: list of bytes -> New(WithSpecialTokens(list)); devices: list of ints -> New(WithDevices(list));
+        loader: (rank_step, fail_merges, null_loader) -> New(WithDataLoader(a loader over the files in data_dir))"""
         self.L = load()
         k = C.c_int(0)
-        if devices is not None:
+        if loader is not None:
+            self.h = self.L.l3h_new_loader(device, data_dir.encode(), loader[0], int(loader[1]), int(loader[2]), C.byref(k))
+        elif devices is not None:
             arr = (C.c_int * len(devices))(*devices)
             self.h = self.L.l3h_new_devices(arr, len(devices), data_dir.encode() if data_dir else None, C.byref(k))
         elif specials is None:

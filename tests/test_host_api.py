@@ -5,9 +5,11 @@ tests/scanner_model.py, on the readers of the reference's scanner_test.go.
 GPU part: the reference's own API tests (tokenizer_test.go, performance_test.go, scanner_test.go) restated
 against llama3::Tokenizer, with the oracle as the expected value wherever the reference test compares against
 its own Encode."""
+import os
 import random
 import struct
 
+import numpy as np
 import pytest
 
 from tests import hostapi, scanner_model
@@ -357,5 +359,70 @@ def test_with_devices_shards_streams(tok, oracle):
                     tok.streams([s], buf_size=256, opts=(True, True))[0] == want))
         assert t.encode(b"Hello world!") == oracle.encode(b"Hello world!", True, True)
         assert t.decode([9906, 1917, 0]) == b"Hello world!" and t.vocab_size() == 128256
+    finally:
+        t.close()
+
+
+def test_data_loader_packs_the_reference_file_formats(tmp_path):
+    # WithDataLoader (options.go:52-60, vocab.go:14-22): tokens + merge map -> the two file formats the C ABI takes.  A loader
+    # over the shipped files must give those files back (the merge priorities only count through their order), and over a
+    # truncated vocabulary with the FULL merge list it must drop the rules that name unknown tokens (decoder.go:61-63).
+    import base64
+    from tests import custom_vocab
+    vocab = open(os.path.join(hostapi.DATA, "vocab_base64.txt"), "rb").read().strip()
+    merges = open(os.path.join(hostapi.DATA, "merges_binary.txt"), "rb").read().strip()
+    def same_vocab(a, b):   # the same token lines (a final newline or not is the same file to decoder.go:16-36)
+        return base64.b64decode(a).rstrip(b"\n") == base64.b64decode(b).rstrip(b"\n")
+
+    def same_merges(a, b, n_pairs=None):   # the same 17-bit pairs; what follows the last whole pair is padding
+        a, b = base64.b64decode(a), base64.b64decode(b)
+        n = min(len(a), len(b)) * 8 // 34 if n_pairs is None else n_pairs
+        bits = lambda x: np.unpackbits(np.frombuffer(x, dtype=np.uint8))[:n * 34]   # noqa: E731
+        return abs(len(a) - len(b)) <= 4 and np.array_equal(bits(a), bits(b))
+
+    for step in (1, 7):
+        v, m = hostapi.pack_loader(rank_step=step)
+        assert same_vocab(v, vocab) and same_merges(m, merges)
+    tv, tm, n_kept = custom_vocab.truncated_vocabulary(30000)
+    tv_full, tm_full, _ = custom_vocab.truncated_vocabulary(30000, full_merges=True)
+    d = tmp_path / "trunc"
+    d.mkdir()
+    (d / "vocab_base64.txt").write_bytes(tv_full)
+    (d / "merges_binary.txt").write_bytes(tm_full)
+    v, m = hostapi.pack_loader(str(d))
+    assert same_vocab(v, tv)
+    # the loader keeps every rule whose two operands exist (the product may be missing: such a rule produces nothing)
+    assert len(base64.b64decode(m)) * 8 // 34 >= n_kept
+    (d / "merges_binary.txt").write_bytes(tm)         # only the rules of the truncated vocabulary: given back as they are
+    v, m = hostapi.pack_loader(str(d))
+    assert same_vocab(v, tv) and same_merges(m, tm, n_kept)
+
+
+@pytest.mark.gpu
+def test_new_with_data_loader(tok, oracle, tmp_path):
+    from tests import custom_vocab
+    from tests.oracle import Oracle
+    with pytest.raises(RuntimeError, match="error kind %d" % hostapi.ERR_CONFIG):
+        hostapi.Tokenizer(0, loader=(1, False, True))                 # WithDataLoader(nil): ConfigError
+    with pytest.raises(RuntimeError, match="error kind %d" % hostapi.ERR_DATA_NOT_FOUND):
+        hostapi.Tokenizer(0, loader=(1, True, False))                 # the loader's LoadMerges fails: New fails with it
+    texts = [b"Hello world!", "Unicode: 你好世界 🦙 don't".encode(), b"<|begin_of_text|>x<|eot_id|>", b"1234567 \n\n  z", b""]
+    t = hostapi.Tokenizer(0, loader=(5, False, False))                # the shipped data through the loader interface
+    try:
+        assert t.vocab_size() == 128256
+        for x in texts:
+            assert t.encode(x) == oracle.encode(x, True, True)
+    finally:
+        t.close()
+    tv, tm, _ = custom_vocab.truncated_vocabulary(30000)
+    d = tmp_path / "trunc"
+    d.mkdir()
+    (d / "vocab_base64.txt").write_bytes(tv)
+    (d / "merges_binary.txt").write_bytes(tm)
+    t, o = hostapi.Tokenizer(0, data_dir=str(d), loader=(1, False, False)), Oracle(tv, tm)
+    try:
+        assert t.vocab_size() == 30256 and t.special(b"<|begin_of_text|>") == (30000, hostapi.ERR_NONE)
+        for x in texts:
+            assert t.encode(x) == o.encode(x, True, True)
     finally:
         t.close()

@@ -433,6 +433,23 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int n, int own_lo, i
 #ifndef L3_TILE_OCC
 #define L3_TILE_OCC 7
 #endif
+// -DL3_PHASE_PROF (tools/build_variant.sh): wall cycles of every phase of the tile kernel, summed over the workgroups of all
+// launches since the last reset, read with l3_debug_phases().  Diagnostic builds only.
+#ifdef L3_PHASE_PROF
+__device__ unsigned long long g_phase[16];
+#define L3_PH_INIT() long long ph_prev = clock64()
+#define L3_PH(i)                                                                   \
+    do {                                                                           \
+        if (threadIdx.x == 0) {                                                    \
+            const long long ph_now = clock64();                                    \
+            atomicAdd(&g_phase[i], (unsigned long long)(ph_now - ph_prev));        \
+            ph_prev = ph_now;                                                      \
+        }                                                                          \
+    } while (0)
+#else
+#define L3_PH_INIT() do {} while (0)
+#define L3_PH(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables T, Workspace W, EncodeArgs A) {
     __shared__ __align__(16) TileLds R;
     __shared__ unsigned long long tmp64[8];
@@ -440,6 +457,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     __shared__ int ccnt[kLenClasses], cm0[kLenClasses];   // short deferred pre-tokens per length class; their first entry
 
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    L3_PH_INIT();
     const uint64_t tile = blockIdx.x;
     const uint64_t t_lo = tile * (uint64_t)kTile;
     const uint64_t t_hi = t_lo + kTile < A.n_bytes ? t_lo + kTile : A.n_bytes;
@@ -490,6 +508,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     if (cls_thread) *reinterpret_cast<uint4*>(&R.b[c0]) = make_uint4(xw[0], xw[1], xw[2], xw[3]);
     if (tid == 0) *reinterpret_cast<uint4*>(&R.b[kRegion]) = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    L3_PH(0);
     if (tid == 0 && d0 > 0) {
         uint64_t pos = A.doc_off[d0 - 1];
         if (pos >= g_lo) atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
@@ -520,6 +539,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         m_apos = aw & valid; m_lt = (aw >> 16) & valid;
     }
     __syncthreads();
+    L3_PH(1);
 
     // -- bytes outside ASCII (generic UTF-8 decode + class table), contraction letters after an apostrophe,
     //    special-token literals after '<' (state_machine.go:36,131-148,310-320; special.go:12)
@@ -578,6 +598,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         h = reinterpret_cast<uint16_t*>(R.bm[B_NX]); h[tid] = (uint16_t)m_nx;
     }
     __syncthreads();
+    L3_PH(2);
 
     // -- start-of-pre-token bits (one wave), digit runs that need more context than the halo holds
     if (wave == 0) {
@@ -591,6 +612,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         }
     }
     __syncthreads();
+    L3_PH(3);
     if (vars[TV_NEED] || vars[TV_MB]) {  // rare: long digit runs / digits outside ASCII
         uint32_t edge = 0;
         const bool need = vars[TV_NEED] != 0, mbd = vars[TV_MB] != 0;
@@ -678,6 +700,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         }
     }
     __syncthreads();
+    L3_PH(4);
 
     int32_t* res = reinterpret_cast<int32_t*>(&R.bm[B_LIVE][0]);
     int32_t* out0 = W.stream + tile * (uint64_t)kTileCap;
@@ -760,6 +783,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         }
     }
     __syncthreads();
+    L3_PH(5);
     // generic loop: the listed pre-tokens, or all of them again when the list overflowed (then the counters restart)
     const bool rare_all = (uint32_t)vars[TV_NRARE] > (uint32_t)kRareCap;   // uniform over the workgroup
     if (rare_all) {
@@ -807,6 +831,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         }
     }
     __syncthreads();
+    L3_PH(6);
     // space in the entry lists: one returning atomic per length class the tile uses (lanes 0..15) and one for the slow
     // list (lane 16), issued here and first needed after the document loop below, so that the round trip overlaps
     const uint32_t sub = (uint32_t)(tile & 3u);
@@ -847,6 +872,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         vars[TV_SLOW0] = (int)m0_r;
     }
     __syncthreads();
+    L3_PH(7);
     {
         const uint32_t s0 = (uint32_t)vars[TV_SLOW0];
         int32_t* out = W.stream + tile * (uint64_t)kTileCap;
@@ -949,6 +975,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             out[k] = item;
         }
     }
+    L3_PH(8);
 }
 
 // ---- the merge kernel: short deferred pre-tokens, one lane each -------------------------------------------
@@ -2973,3 +3000,16 @@ hipError_t launch_decode(const uint32_t* tok_off, const uint8_t* tok_bytes, int 
 }
 
 }  // namespace l3
+
+#ifdef L3_PHASE_PROF
+extern "C" int l3_debug_phases(unsigned long long* out, int n, int reset) {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(l3::g_phase), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 16; i++) out[i] = h[i];
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(l3::g_phase), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
