@@ -722,6 +722,8 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             bool probe[kLookU], again[kLookU];
 #pragma unroll
             for (int u = 0; u < kLookU; u++) {
+                // (skipping the slots of a wave whose 64 pre-tokens all lie past the end -- 3 of 16 wave-slots at ~800
+                // pre-tokens a tile -- was measured: the scalar branches cost the tile kernel 3 %, round 2)
                 // straight-line code on a clamped index (lanes past the end redo the last pre-token and are masked
                 // at the stores): the branches this replaces cost more scalar work than the lanes they saved
                 const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
