@@ -56,8 +56,9 @@ const char* l3_last_error(const l3_ctx* ctx);
  * Document i's ids are out_tok[out_off[i] .. out_off[i+1]); *n_tok = out_off[n_docs].
  * Bytes may be arbitrary (invalid UTF-8 is handled as Go's []rune conversion does, state_machine.go:36).
  * Host pointers.  If out_cap is too small L3_E_OUTPUT_CAP is returned with *n_tok = the size needed; out_off is still
- * filled in, the contents of out_tok are unspecified.  Batches of 16 MiB and more whose text and out_tok lie in page-locked
- * memory are moved in pieces of whole documents, so that uploads, kernels and downloads overlap. */
+ * filled in, the contents of out_tok are unspecified.  Batches of 16 MiB and more are moved in pieces of whole documents, so
+ * that uploads, kernels and downloads overlap: directly when text / out_tok lie in page-locked memory (l3_host_alloc),
+ * else through page-locked staging buffers of the context that a few host threads fill and drain. */
 int l3_encode_batch(l3_ctx* ctx, const uint8_t* text, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                     int32_t* out_tok, uint64_t out_cap, uint64_t* out_off, uint64_t* n_tok);
 
