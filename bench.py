@@ -67,7 +67,14 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "16")
-    return subprocess.call(cmd, env=env)
+    # Only rank 0's JSON line goes to this process's stdout (the contract: ONE line); whatever else the ranks and the
+    # launcher print on theirs (gloo / RCCL banners) is passed on to stderr.
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        out = sys.stdout if line.startswith("{") and line.rstrip().endswith("}") else sys.stderr
+        out.write(line)
+        out.flush()
+    return proc.wait()
 
 
 def source_digest():
@@ -330,6 +337,48 @@ def main():
             except Exception as e:   # the headline must not die with a side measurement
                 other["error"] = repr(e)
             result["other_configs"] = other
+            side = {}
+            try:
+                # f-2: decode of this rank's last batch of ids (host-pointer call; the figure is the kernels' time by events)
+                wait(submit(steps - 1))
+                torch.cuda.synchronize()
+                o, oo = outs[(steps - 1) & 1]
+                h_off = oo.cpu().numpy().astype(np.uint64)
+                h_ids = o[:int(h_off[-1])].cpu().numpy()
+                ctx.set_profiling(1)
+                dms = []
+                for _ in range(4):
+                    dec, _doff = ctx.decode_batch(h_ids, h_off)
+                    dms.append(ctx.last_timings()["decode"])
+                ctx.set_profiling(False)
+                dms = sorted(dms[1:])[1]
+                side["decode_c2"] = {"ids": int(h_ids.size), "bytes_out": int(dec.size), "kernels_ms": dms,
+                                     "out_gb_per_s": dec.size / dms / 1e6,
+                                     "frac": (4 * h_ids.size + dec.size + 16 * h_off.size) / dms / 1e6 / HBM_PEAK_GBS,
+                                     "note": "ids of the last batch incl. BOS/EOS -> bytes; kernels only, by HIP events"}
+                # host-fed (PCIe-inclusive, never `value`): l3_encode_batch on one batch held in pageable host memory
+                h_text = d_text[:n_bytes].cpu().numpy()
+                h_doff = (np.arange(n_docs + 1, dtype=np.uint64) * np.uint64(DOC_BYTES))
+                h_out = np.zeros(out_cap, dtype=np.int32)        # (touched once, so that the timed calls fault no pages in)
+                h_ooff = np.zeros(n_docs + 1, dtype=np.uint64)
+                h_n = C.c_uint64(0)
+
+                def host_call():
+                    rc = ctx.lib.l3_encode_batch(ctx.h, h_text.ctypes.data, h_doff.ctypes.data, n_docs, flags, h_out.ctypes.data,
+                                                 out_cap, h_ooff.ctypes.data, C.byref(h_n))
+                    if rc != capi.L3_OK:
+                        raise RuntimeError("l3_encode_batch failed: %d" % rc)
+                for _ in range(3):
+                    host_call()
+                h0 = time.perf_counter()
+                for _ in range(6):
+                    host_call()
+                hdt = (time.perf_counter() - h0) / 6
+                side["host_fed_pageable_c2"] = {"ms": hdt * 1e3, "input_gb_per_s": n_bytes / hdt / 1e9,
+                                                "note": "upload + kernels + download through l3_encode_batch, caller buffers pageable"}
+            except Exception as e:
+                side["error"] = repr(e)
+            result["side_figures"] = side
 
         if not args.no_cpu_baseline:
             from tests.oracle import Oracle
