@@ -12,11 +12,18 @@
 //                  one stream item per pre-token: its id, or a placeholder of a deferred pre-token
 //   merge_kernel   one lane per short deferred pre-token (<= 64 bytes): greedy merge in an LDS slot (bpe.go:36-71);
 //                  its last workgroups make the wave-per-entry pass over the slow list (mid_pass)
-//   slow_kernel    one workgroup per remaining deferred pre-token (long, or ending beyond the halo): exact
-//                  round-based parallel greedy merge
+//                  and cut the long ones into window items (prep_entry)
+//   slow_kernel    the remaining deferred pre-tokens (long, invalid UTF-8, or ending beyond the halo) as independent
+//                  WINDOW items of 1,920 symbols: cut points where no vocabulary entry can span, every piece merged by
+//                  the exact round-based parallel greedy merge, token ids into a sparse per-symbol image; pieces of
+//                  32,768 symbols and more are listed for the grid-wide merge (l3_giant.hip, driven by the host)
 //   block_totals_kernel, scan_kernel   per-tile output bases: totals per 1,024 tiles, their exclusive scan
-//                  (one launch with the last workgroup scanning was tried: no faster, two fences more)
-//   emit_kernel    scatter to the final token array, per-document offsets, BOS/EOS (tokenizer.go:225-262)
+//                  (one launch with the last workgroup scanning was tried: no faster, two fences more); the launch of
+//                  the first also carries the finish_window workgroups that compact the window images
+//   emit_kernel    scatter to the final token array, per-document offsets, BOS/EOS (tokenizer.go:225-262);
+//   emit_generic_kernel   the tiles the fast one flags
+//   status_out_kernel     the status word to page-locked host memory, cleared for the next batch
+//   decode_sum / decode_scan / decode_write_kernel   ids -> bytes in blocks of 4,096 ids (tokenizer.go:339-354)
 //
 // All cross-workgroup data flows through kernel boundaries on one stream; atomics are used only
 // for counters / appends that later kernels read.
@@ -1813,9 +1820,6 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
     }
     const uint8_t* const wb = P.wraw + shift;   // wb[j] = symbol o0 + j, j < avail (what lies behind is unspecified)
     __syncthreads();
-#if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 0
-    return 0;
-#endif
     // Match length at each of this thread's consecutive positions.  A walk is a chain of dependent table probes (is the
     // string one byte longer still a prefix of an entry?), and a wave waits for its longest chain; so a step probes
     // FOUR lengths at once -- the bytes are in LDS, the hashes of the longer strings cost nothing to form ahead, and
@@ -1926,9 +1930,6 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
     __syncthreads();
     if (tid == 0) first[k] = k_total ? o0 + (uint32_t)P.pl[0] : 0xFFFFFFFFu;   // (for pieces whose end is looked up later)
     if (k_total == 0) return 0;   // (uniform) the whole window lies inside a piece that started earlier
-#if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 1
-    return 0;
-#endif
     // where the last piece ends: at the end of the pre-token, at the window's end if that is a cut, else at the first cut
     // behind it -- found by walking on, one position per thread and step.  After kTailSteps steps without a cut the
     // piece is LISTED for the grid-wide merge with its end left open (the later windows record their first cuts:
@@ -1989,9 +1990,6 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
         }
         __syncthreads();
     }
-#if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 2
-    return 0;
-#endif
     const uint32_t range_hi = lo + (uint32_t)kWin;   // slots from here on belong to the next window's counter
     const bool whole_single = !last_deferred && k_total == 1 && lo == 0 && last_end == L;   // the pre-token is one piece (o0 == 0)
     const uint32_t n_pieces = last_deferred ? k_total - 1u : k_total;   // (the listed one is not this kernel's any more)
@@ -2012,9 +2010,6 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
         n_multi += tot;
     }
     __syncthreads();
-#if defined(L3_SLOW_STOP) && L3_SLOW_STOP == 3
-    return 0;
-#endif
 #pragma unroll 1
     for (uint32_t i0 = 0; i0 < n_multi; i0 += kSlowThreads) {
         const bool have = i0 + (uint32_t)tid < n_multi;
@@ -2583,8 +2578,9 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
         }
     }
     __syncthreads();
-    // long runs of tokens from the pool: copied by the whole workgroup (more than 64 tokens = more than 64 bytes,
-    // so one tile holds fewer than kEmitQueue of them)
+    // long runs of tokens from the pool: copied by the whole workgroup.  (A tile that reaches this point stages at most
+    // kStage tokens -- tiles with more were flagged for the generic kernel above --, so it holds fewer than
+    // kStage / 65 < kEmitQueue pre-tokens of more than 64 tokens.)
     const uint32_t qn = q_n < kEmitQueue ? q_n : kEmitQueue;
     for (uint32_t qi = 0; qi < qn; qi++) {
         uint64_t po; uint32_t cn; bool il;
