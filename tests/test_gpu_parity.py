@@ -411,3 +411,24 @@ def test_decode_round_trip(ctx, oracle):
     out, ooff = ctx.decode_batch(ids, np.array([0, 100, 100, 5000], dtype=np.uint64))
     assert out.tobytes() == oracle.decode(ids.tolist())
     assert int(ooff[1]) == len(oracle.decode(ids[:100].tolist())) and ooff[1] == ooff[2]
+
+
+def test_generic_emit_with_documents_inside_heavy_tiles(ctx, oracle):
+    # tiles with more tokens than the fast emit kernel stages (invalid bytes: three tokens each) go to the generic emit
+    # kernel; documents that start inside such tiles are counted per item there.  Found by the soak (round 2): the
+    # counters were cleared and incremented without a barrier between, and a document start could be lost -- rarely,
+    # so the batch is run many times.
+    from tokenizer_amd import capi
+    rng = np.random.default_rng(9)
+    docs = []
+    for i in range(600):
+        docs.append(bytes(rng.integers(128, 256, int(rng.integers(200, 5000)), dtype=np.uint8)))
+        docs.append(b"rxzc muaahon " + bytes(rng.integers(97, 123, int(rng.integers(1, 40)), dtype=np.uint8)))
+        if i % 7 == 0:
+            docs.append(b"")
+    text, off = capi.pack_docs(docs)
+    exp_tok, exp_off = oracle.encode_batch(text, off, True, False, threads=16)
+    for rep in range(40):
+        tok, toff = ctx.encode_batch(text, off, True, False)
+        assert np.array_equal(toff, exp_off) and np.array_equal(tok, exp_tok), rep
+    assert ctx.last_counters()["tiles"] > 300

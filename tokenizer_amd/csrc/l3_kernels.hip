@@ -2622,6 +2622,8 @@ __device__ void emit_tile_generic(const Workspace& W, const EncodeArgs& A, uint6
     if (tid == 0) q_n = 0;
     // tokens before this tile: scanned block base + the tiles of the block that precede it
     const unsigned long long base = W.tile_base[tile / kScanBlock] + W.tile_rec[tile].pre;
+    __syncthreads();   // (the counters are cleared by other threads than those that count: without this barrier a document
+                       // start was lost once in some ten thousand heavy tiles, and the tile's tokens landed one slot early)
     for (uint64_t d = d_lo + tid; d < d_hi; d += kTileThreads) atomicAdd(&docinc[W.doc_item[d]], 1u);
     __syncthreads();
 
