@@ -60,24 +60,34 @@ L3_HD void pair_hash2(uint32_t a, uint32_t b, uint32_t log2_buckets, uint32_t* b
 struct alignas(16) VocabSlot { uint32_t w[4]; };
 constexpr uint32_t kVocabEmpty = 0xFFFFFFFFu;
 constexpr int kVocabInline = 12;
+L3_HD uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 L3_HD uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
 }
-L3_HD uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
-// short strings (<= 12 bytes): two independent hashes of their three little-endian words, built from full-rate
-// 24-bit multiplies.  Each word is folded to 24 bits first, differently for the two hashes, so that no pair of
-// words collides in both.
-L3_HD void vocab_hash_short2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len, uint32_t log2_buckets, uint32_t* b1,
-                             uint32_t* b2) {
-    uint32_t x = mul24(w0 ^ (w0 >> 13), 0x9E3779u) + mul24(w1 ^ (w1 >> 13), 0x85EBCBu) + mul24(w2 ^ (w2 >> 13), 0xC2B2AFu) +
-                 mul24(len, 0x27D4EBu);
+// short strings (<= 12 bytes): two independent hashes of their three little-endian words (zero padded) and their length.
+// The FIRST choice is the one nearly every probe ends with (tokens are placed in id order and keep their first-choice
+// bucket when it is free), so it is made of as few instructions as a usable hash allows: two rotates, one three-input
+// xor, one multiply-add, one shift-xor, one 24-bit multiply, one shift = 8 full-rate operations on gfx950 (the hash it
+// replaced took 18).  Parameters chosen by counting first-choice collisions over the 123,039 short entries of the Llama-3
+// vocabulary: 13,621 (338 among ids < 20,000) against 14,436 expected of an ideal hash and 15,166 (554) of the old one.
+// The SECOND choice is only computed for the strings that were not found in their first bucket (a few per cent).
+L3_HD uint32_t vocab_hash_short_a(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len, uint32_t log2_buckets) {
+    uint32_t t = w0 ^ rotl32(w1, 13) ^ rotl32(w2, 26);
+    t += mul24(len, 0x9E3779u);
+    t ^= t >> 12;
+    return mul24(t, 0xB5297Bu) >> (32 - log2_buckets);
+}
+L3_HD uint32_t vocab_hash_short_b(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len, uint32_t log2_buckets) {
     uint32_t y = mul24(w0 ^ (w0 >> 9), 0x7FEB35u) + mul24(w1 ^ (w1 >> 9), 0x846CA7u) + mul24(w2 ^ (w2 >> 9), 0xD6E8FFu) +
                  mul24(len, 0x165667u);
-    x ^= x >> 15;
     y ^= y >> 14;
-    *b1 = mul24(x, 0xB5297Bu) >> (32 - log2_buckets);
-    *b2 = mul24(y, 0x68E31Du) >> (32 - log2_buckets);
+    return mul24(y, 0x68E31Du) >> (32 - log2_buckets);
+}
+L3_HD void vocab_hash_short2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len, uint32_t log2_buckets, uint32_t* b1,
+                             uint32_t* b2) {
+    *b1 = vocab_hash_short_a(w0, w1, w2, len, log2_buckets);
+    *b2 = vocab_hash_short_b(w0, w1, w2, len, log2_buckets);
 }
 // longer strings: two running hashes over the little-endian words of the (expanded) pre-token, the last
 // word zero padded

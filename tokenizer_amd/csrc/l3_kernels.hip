@@ -181,8 +181,13 @@ typedef unsigned long long u64;
 enum { B_ST = 0, B_SPS, B_INV, B_DS, B_LIVE, B_RS = B_LIVE, B_L, B_N, B_NL, B_SP, B_WS, B_APOS, B_NX, B_CE2, B_CE3,
        B_SPB, B_SPE, B_CONTN, B_COUNT };
 
-constexpr int kResCap = (B_COUNT - B_LIVE) * (kWords + 2) * 2;  // stream items staged in LDS (the rest goes straight to HBM)
-constexpr int kRareCap = 512;
+// The bitmap rows from B_LIVE on, reused by the lookup phase: a list of the pre-tokens its first stage does not settle
+// (16-bit list indices; from the front those that missed their first bucket, from the back the rare kinds) and the notes
+// of the deferred ones (32-bit).  A tile that overflows either starts over in the general way (see the kernel).
+constexpr int kLiveBytes = (B_COUNT - B_LIVE) * (kWords + 2) * 8;
+constexpr int kLstCap = 1920, kDeferCap = 756;
+static_assert(kLstCap * 2 + kDeferCap * 4 <= kLiveBytes && (kLstCap * 2) % 4 == 0, "work lists of the lookup phase must fit the dead bitmap rows");
+constexpr uint32_t kOpenEnd = 0xFFFFu;   // TileLds::list[n_pre]: the last own pre-token ends beyond what the halo decides
 // Short deferred pre-tokens are binned by length: shard = length class * 4 + (tile & 3), class = min(len, 16) - 1.
 // The 64 lanes of a merge wave then walk merge chains of about the same length (the chain of a wave is that of
 // its longest lane), which cut the merge kernel's time by a third; (tile & 3) spreads a class's atomics over
@@ -194,15 +199,14 @@ struct TileLds {
     uint8_t b[kRegion + 16];
     u64 bm[B_COUNT][kWords + 2];
     union {
-        uint16_t list[kTile];  // compacted own pre-token starts (region-local offsets)
+        uint16_t list[kTile + 2];  // compacted own pre-token starts (region-local offsets) + the end of the last one
         uint4 ctab[256];       // before that: class bits of every byte value, see the classification step
     };
     uint16_t wpre[kWords + 1]; // own pre-token starts before each mask word
-    uint16_t rare[kRareCap];   // list index k of the pre-tokens left to the second lookup pass
 };
 constexpr int kListPer = 16;
 static_assert(kListPer * kTileThreads >= kTile && 64 % kListPer == 0 && kBack % kListPer == 0, "list compaction geometry");
-enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NSLOW, TV_SLOW0, TV_NRARE, TV_ANYINV, TV_LASTE, TV_OWNINV, TV_COUNT = 12 };
+enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NSLOW, TV_SLOW0, TV_NAB, TV_ANYINV, TV_NDEF, TV_OWNINV, TV_ANYSPS, TV_COUNT = 12 };
 
 struct TileSrc {  // byte source over the tile's LDS image, LOCAL coordinates [0, n)
     const TileLds* R;
@@ -437,8 +441,91 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int n, int own_lo, i
     return flags;
 }
 
+// inclusive sum scan over the wave with DPP row shifts and row broadcasts (six v_add_u32_dpp; no LDS crossbar)
+__device__ __forceinline__ uint32_t wave_iscan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// One pre-token [s, e) (e < 0: it ends beyond what the halo decides) the long way: special token, whole-string probe of any
+// length (bpe.go:27-33), or deferral.  Returns 0 and the token id in *item, or the kind of deferral (*item untouched): 1 = up
+// to kLaneMax valid bytes (a lane of the merge kernel), 2 = slow, 3 = slow and known to be valid UTF-8.
+__device__ __forceinline__ uint32_t tile_generic_item(const Tables& T, const TileLds& R, const TileSrc& src, const uint32_t* bw, int s,
+                                                      int e, int32_t* item) {
+    if ((R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull) {
+        int canon = 0;
+        special_match(src, s, &canon);
+        *item = T.special_id[canon];
+        return 0u;
+    }
+    const int len = e - s;
+    const bool valid = e >= 0 && !any_bit_in(R.bm[B_INV], s, e);
+    if (valid && len <= kMaxTokenBytes) {
+        const uint32_t* wp = bw + (s >> 2);
+        const uint32_t sh = (uint32_t)(s & 3) * 8u;
+        const uint32_t nw = ((uint32_t)len + 3u) >> 2;
+        const uint32_t tail = (len & 3) ? (1u << ((len & 3) * 8)) - 1u : 0xFFFFFFFFu;
+        const int32_t id = vocab_lookup_words(T, [&](uint32_t i) {
+            uint32_t x = __funnelshift_r(wp[i], wp[i + 1], sh);
+            return i + 1 == nw ? x & tail : x;
+        }, (uint32_t)len);
+        if (id >= 0) { *item = id; return 0u; }
+    }
+    if (valid && len <= kLaneMax) return 1u;
+    return valid ? 3u : 2u;
+}
+
+// Entry record of the deferred pre-token k of a tile (list[k] .. list[k + 1]) in the global lists; returns its stream item.
+// slow: entry s0 + ord of the slow list; else entry cm0[c] + ord of the tile's shard of length class c.
+__device__ __forceinline__ int32_t tile_deferred_record(const Workspace& W, const TileLds& R, const uint32_t* bw, const int* cm0,
+                                                        uint64_t g_lo, uint64_t tile, uint32_t sub, uint32_t s0, uint32_t k, bool slow,
+                                                        uint32_t ord, uint32_t c, uint32_t valid) {
+    const uint32_t s = R.list[k], ev = R.list[k + 1u];
+    uint64_t ei;
+    if (slow) {
+        ei = (uint64_t)s0 + ord;
+        if (ei < W.slow_cap) {
+            SlowEntry se;
+            se.start = g_lo + (uint64_t)s;
+            se.win0 = 0;
+            se.len = ev == kOpenEnd ? 0u : ev - s;
+            se.tile = (uint32_t)tile;
+            se.count = valid;   // in: 1 = known to be valid UTF-8
+            se.pad = 0; se.pool_off = 0;
+            W.slow[ei] = se;
+        }
+        ei += kSlowBase;
+    } else {
+        const uint64_t li = (uint64_t)(uint32_t)cm0[c] + ord;
+        ei = (uint64_t)(c * 4u + sub) * W.miss_shard_cap + li;
+        if (li < W.miss_shard_cap) {
+            MissIn mi;
+            mi.start = g_lo + (uint64_t)s;
+            mi.tile = (uint32_t)tile;
+            mi.len = ev - s;
+            {   // the first 16 bytes ride along (LDS image, unaligned start), so the merge kernel reads no text
+                const uint32_t* wp = bw + (s >> 2);
+                const uint32_t sh = s * 8u;
+                const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3], x4 = wp[4];
+                mi.w[0] = __funnelshift_r(x0, x1, sh); mi.w[1] = __funnelshift_r(x1, x2, sh);
+                mi.w[2] = __funnelshift_r(x2, x3, sh); mi.w[3] = __funnelshift_r(x3, x4, sh);
+            }
+            W.miss_in[ei] = mi;
+        }
+    }
+    return -2 - (int32_t)(uint32_t)ei;
+}
+
 #ifndef L3_TILE_OCC
 #define L3_TILE_OCC 7
+#endif
+#ifndef L3_LOOK_U
+#define L3_LOOK_U 4
 #endif
 // -DL3_PHASE_PROF (tools/build_variant.sh): wall cycles of every phase of the tile kernel, summed over the workgroups of all
 // launches since the last reset, read with l3_debug_phases().  Diagnostic builds only.
@@ -455,13 +542,29 @@ __device__ unsigned long long g_phase[16];
     } while (0)
 #else
 #define L3_PH_INIT() do {} while (0)
+#ifdef L3_TILE_EXIT
+// -DL3_TILE_EXIT=i (tools/build_variant.sh): the tile kernel ends behind phase i with a well-formed EMPTY tile (no items, every
+// document of the tile at item 0), so that the kernels behind it run on.  Differences of SQ_INSTS_* between consecutive
+// variants are the instruction counts of the phases (profiles/r03_tile_budget.md).  Diagnostic builds only.
+#define L3_PH(i)                                                                                                   \
+    do {                                                                                                           \
+        if (L3_TILE_EXIT == (i)) {                                                                                 \
+            if (threadIdx.x == 0) { W.tile_items[blockIdx.x] = 0; W.tile_first[blockIdx.x] = kNoFirst; }           \
+            const uint64_t de_ = blockIdx.x + 1 == gridDim.x ? A.n_docs + 1 : (uint64_t)W.tile_doc0[blockIdx.x + 1]; \
+            for (uint64_t d_ = (uint64_t)W.tile_doc0[blockIdx.x] + threadIdx.x; d_ < de_; d_ += kTileThreads) W.doc_item[d_] = 0; \
+            return;                                                                                                \
+        }                                                                                                          \
+    } while (0)
+#else
 #define L3_PH(i) do {} while (0)
+#endif
 #endif
 __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables T, Workspace W, EncodeArgs A) {
     __shared__ __align__(16) TileLds R;
     __shared__ unsigned long long tmp64[8];
     __shared__ int vars[TV_COUNT];
     __shared__ int ccnt[kLenClasses], cm0[kLenClasses];   // short deferred pre-tokens per length class; their first entry
+    __shared__ uint4 mk[kVocabInline + 1];
 
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     L3_PH_INIT();
@@ -496,7 +599,12 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     for (int i = tid; i < kWords + 2; i += kTileThreads) {
         R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0; R.bm[B_CE2][i] = 0; R.bm[B_CE3][i] = 0;
     }
-    if (tid == 0) { vars[TV_NSLOW] = 0; vars[TV_NRARE] = 0; vars[TV_ANYINV] = 0; }
+    if (tid == 0) { vars[TV_NSLOW] = 0; vars[TV_NAB] = 0; vars[TV_NDEF] = 0; vars[TV_ANYINV] = 0; vars[TV_ANYSPS] = 0; }
+    if (tid <= kVocabInline) {   // mask of the first `tid` bytes of three words + the length tag of a vocabulary slot
+        const uint32_t l = (uint32_t)tid;
+        mk[tid] = make_uint4(l >= 4u ? 0xFFFFFFFFu : (1u << (8u * l)) - 1u, l >= 8u ? 0xFFFFFFFFu : (l > 4u ? (1u << (8u * (l - 4u))) - 1u : 0u),
+                             l >= 12u ? 0xFFFFFFFFu : (l > 8u ? (1u << (8u * (l - 8u))) - 1u : 0u), l << 17);
+    }
     if (tid < kLenClasses) ccnt[tid] = 0;
     {   // class table entry of byte value `tid` (state_machine.go:310-320 for ASCII: letters, Nd digits, unicode.IsSpace)
         const uint32_t v = (uint32_t)tid;
@@ -588,6 +696,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                 atomicOr(&R.bm[B_SPE][q >> 6], 1ull << (q & 63));
                 atomicOr(&R.bm[B_SPE][(q + len) >> 6], 1ull << ((q + len) & 63));
                 if (T.special_id[canon] != 0) {  // tokenizer.go:236: only a piece whose lookup is non-zero is special
+                    vars[TV_ANYSPS] = 1;   // (every writer stores the same value)
                     atomicOr(&R.bm[B_SPS][q >> 6], 1ull << (q & 63));
                     for (int k = 1; k < len; k++) atomicOr(&R.bm[B_SPB][(q + k) >> 6], 1ull << ((q + k) & 63));
                 }
@@ -678,12 +787,13 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     const u64* ST = R.bm[B_ST];
 
     // -- compacted list of own pre-token starts (kListPer byte positions per thread; own_lo is 0 or kBack, so a
-    //    thread's positions never straddle a 64-bit mask word)
+    //    thread's positions never straddle a 64-bit mask word).  list[n_pre] = end of the last own pre-token (the others
+    //    end where the next one starts), kOpenEnd when it lies beyond what the look-ahead halo decides
     {
-        if (tid == kTileThreads - 1) {   // end of the last own pre-token (the others end where the next one starts):
+        if (tid == kTileThreads - 1) {
             int e = find_next_bit64(ST, own_hi, eval_hi);   // the first start past the own range
             if (e < 0 && hard) e = n;
-            vars[TV_LASTE] = e;
+            R.list[n_pre] = e < 0 ? (uint16_t)kOpenEnd : (uint16_t)e;
         }
         const int pos = own_lo + tid * kListPer;
         if (pos < own_hi) {
@@ -709,138 +819,157 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     __syncthreads();
     L3_PH(4);
 
-    int32_t* res = reinterpret_cast<int32_t*>(&R.bm[B_LIVE][0]);
+    // The bitmap rows from B_LIVE on are dead by now: they hold the two work lists of the lookup phase.
+    uint16_t* lst = reinterpret_cast<uint16_t*>(&R.bm[B_LIVE][0]);          // [kLstCap]: from the front the pre-tokens that
+                                                                            // missed their first bucket, from the back the rest
+    uint32_t* defer = reinterpret_cast<uint32_t*>(lst + kLstCap);           // [kDeferCap]: the deferred pre-tokens
     int32_t* out0 = W.stream + tile * (uint64_t)kTileCap;
+    const uint32_t* bw = reinterpret_cast<const uint32_t*>(R.b);
     // -- per pre-token: special id / whole-string vocabulary probe (bpe.go:27-33) / defer.  One stream item each.
-    //    The common case (up to 12 valid bytes, no special token) is done kLookU pre-tokens per thread at a time, in
-    //    stages, so that the table loads of a whole batch are in flight together: a tile is latency-bound, not
-    //    issue-bound.  Everything else is only listed here and done by the generic loop below, densely packed.
+    //    Stage 1, every pre-token: up to 12 bytes, valid UTF-8, no special token = the common case.  Words straight from
+    //    the LDS image, masked by a table row per length, the CHEAP first-choice hash, one 16-byte slot load, kLookU
+    //    pre-tokens per thread in flight.  A hit is stored at once (the 64 lanes of a wave hold consecutive items: a
+    //    coalesced store).  What is not settled is listed: missed first bucket -> front of `lst`, everything else -> back.
     {
-        const bool any_inv = vars[TV_ANYINV] != 0;
-        const int last_e = vars[TV_LASTE];
-#ifndef L3_LOOK_U
-#define L3_LOOK_U 4
-#endif
+        const bool complex_tile = vars[TV_ANYINV] != 0 || vars[TV_ANYSPS] != 0;   // uniform
         constexpr int kLookU = L3_LOOK_U;
 #pragma unroll 1
         for (uint32_t base = 0; base < n_pre; base += kTileThreads * kLookU) {
-            uint32_t w0[kLookU], w1[kLookU], w2[kLookU], ln[kLookU], hb2[kLookU];
+            uint32_t a0[kLookU], a1[kLookU], a2[kLookU], tag[kLookU];
             VocabSlot sl[kLookU];
-            bool probe[kLookU], again[kLookU];
+            uint32_t m_fast = 0, m_a = 0, m_b = 0;   // bit u: probed / goes to the front list / goes to the back list
 #pragma unroll
             for (int u = 0; u < kLookU; u++) {
-                // (skipping the slots of a wave whose 64 pre-tokens all lie past the end -- 3 of 16 wave-slots at ~800
-                // pre-tokens a tile -- was measured: the scalar branches cost the tile kernel 3 %, round 2)
-                // straight-line code on a clamped index (lanes past the end redo the last pre-token and are masked
-                // at the stores): the branches this replaces cost more scalar work than the lanes they saved
+                // straight-line code on a clamped index (lanes past the end redo the last pre-token and are masked at the
+                // stores): branches here cost more scalar work than the lanes they save, and keep the loads apart
                 const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
-                const bool in = k < n_pre;
-                const uint32_t kk = in ? k : n_pre - 1u;
-                const int s = R.list[kk];
-                const int e_next = (int)R.list[kk + 1u < n_pre ? kk + 1u : kk];
-                const int e = kk + 1u < n_pre ? e_next : last_e;
-                const int len = e - s;
-                const bool special = (R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull;
-                const bool inval = any_inv && e >= 0 && any_bit_in(R.bm[B_INV], s, e);
-                const bool rare = special || e < 0 || inval || len > kVocabInline;
-                if (in && rare) {
-                    const uint32_t idx = (uint32_t)atomicAdd(&vars[TV_NRARE], 1);
-                    if (idx < (uint32_t)kRareCap) R.rare[idx] = (uint16_t)k;
-                }
-                // little-endian words of the pre-token straight from the LDS image (unaligned start), bytes past its
-                // length masked off: word j keeps min(max(len - 4j, 0), 4) bytes
-                const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
-                const uint32_t sh = (uint32_t)(s & 3) * 8u;
+                const uint32_t kk = k < n_pre ? k : n_pre - 1u;
+                const uint32_t s = R.list[kk], e = R.list[kk + 1u];
+                const uint32_t len = e - s;                     // (an open end gives a huge value)
+                const uint4 m = mk[len < (uint32_t)kVocabInline ? len : (uint32_t)kVocabInline];
+                const uint32_t* wp = bw + (s >> 2);
+                const uint32_t sh = s * 8u;                      // v_alignbit takes the low five bits
                 const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
-                const int l0 = len < 0 ? 0 : (len > 12 ? 12 : len);
-                const uint32_t t0 = (uint32_t)(l0 > 4 ? 4 : l0), t1 = (uint32_t)(l0 > 8 ? 4 : (l0 > 4 ? l0 - 4 : 0)),
-                               t2 = (uint32_t)(l0 > 8 ? l0 - 8 : 0);
-                const uint32_t a0 = __funnelshift_r(x0, x1, sh) & (uint32_t)((1ull << (8u * t0)) - 1ull);
-                const uint32_t a1 = __funnelshift_r(x1, x2, sh) & (uint32_t)((1ull << (8u * t1)) - 1ull);
-                const uint32_t a2 = __funnelshift_r(x2, x3, sh) & (uint32_t)((1ull << (8u * t2)) - 1ull);
-                w0[u] = a0; w1[u] = a1; w2[u] = a2; ln[u] = (uint32_t)l0;
-                uint32_t hb1;
-                vocab_hash_short2(a0, a1, a2, (uint32_t)l0, T.vocab_log2, &hb1, &hb2[u]);
-                sl[u] = T.vocab_slots[hb1];   // (in bounds whatever the lane holds)
-                probe[u] = in && !rare;
-            }
-#pragma unroll
-            for (int u = 0; u < kLookU; u++) {   // first choice missed: second bucket (tokens that lost their first choice, non-tokens)
-                again[u] = false;
-                if (probe[u]) {
-                    const bool hit = (sl[u].w[3] & ~0x1FFFFu) == (ln[u] << 17) && sl[u].w[0] == w0[u] && sl[u].w[1] == w1[u] && sl[u].w[2] == w2[u];
-                    if (!hit) { sl[u] = T.vocab_slots[hb2[u]]; again[u] = true; }
+                a0[u] = __funnelshift_r(x0, x1, sh) & m.x;
+                a1[u] = __funnelshift_r(x1, x2, sh) & m.y;
+                a2[u] = __funnelshift_r(x2, x3, sh) & m.z;
+                tag[u] = m.w;
+                bool fast = len - 1u < (uint32_t)kVocabInline;
+                if (complex_tile) {   // (uniform branch)
+                    const bool special = (R.bm[B_SPS][s >> 6] >> (s & 63u)) & 1ull;
+                    const bool inval = fast && any_bit_in(R.bm[B_INV], (int)s, (int)e);
+                    fast = fast && !special && !inval;
                 }
+                const bool in = k < n_pre;
+                if (in && fast) m_fast |= 1u << u;
+                if (in && !fast) m_b |= 1u << u;
+                sl[u] = T.vocab_slots[vocab_hash_short_a(a0[u], a1[u], a2[u], len, T.vocab_log2)];   // (in bounds whatever the lane holds)
             }
 #pragma unroll
             for (int u = 0; u < kLookU; u++) {
-                if (probe[u]) {
+                const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
+                const uint32_t diff = (sl[u].w[0] ^ a0[u]) | (sl[u].w[1] ^ a1[u]) | (sl[u].w[2] ^ a2[u]) | ((sl[u].w[3] ^ tag[u]) & ~0x1FFFFu);
+                if ((m_fast >> u) & 1u) {
+                    if (diff == 0) out0[k] = (int32_t)(sl[u].w[3] & 0x1FFFFu);
+                    else m_a |= 1u << u;
+                }
+            }
+            // one scan per wave for both lists (the two counts packed in one word), one LDS atomic per wave
+            const uint32_t cnt_a = (uint32_t)__popc(m_a), cnt_b = (uint32_t)__popc(m_b);
+            const uint32_t inc = wave_iscan_dpp(cnt_a | (cnt_b << 16));
+            const uint32_t tot = __builtin_amdgcn_readlane(inc, 63);
+            if (tot) {   // uniform over the wave
+                uint32_t basep = 0;
+                if (lane == 63) basep = atomicAdd(reinterpret_cast<uint32_t*>(&vars[TV_NAB]), tot);
+                basep = __builtin_amdgcn_readlane(basep, 63);
+                uint32_t pa = (basep & 0xFFFFu) + (inc & 0xFFFFu) - cnt_a;
+                uint32_t pb = (basep >> 16) + (inc >> 16) - cnt_b;
+#pragma unroll
+                for (int u = 0; u < kLookU; u++) {
                     const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
-                    const bool hit = (sl[u].w[3] & ~0x1FFFFu) == (ln[u] << 17) && sl[u].w[0] == w0[u] && sl[u].w[1] == w1[u] && sl[u].w[2] == w2[u];
-                    int32_t item;
-                    if (hit) item = (int32_t)(sl[u].w[3] & 0x1FFFFu);
-                    else {   // <= 12 valid bytes: a lane of the merge kernel does it; class and ordinal within the tile's class
-                        const uint32_t c = len_class(ln[u]);
-                        item = -2 - (int32_t)((c << 12) | (uint32_t)atomicAdd(&ccnt[c], 1));
-                    }
-                    // deferred: the local ordinal for now, replaced below by the global entry index.  Staged in LDS (the
-                    // bitmap rows that are dead by now); text of one- and two-byte pre-tokens can exceed it and goes
-                    // straight to HBM
-                    if (k < (uint32_t)kResCap) res[k] = item; else out0[k] = item;
+                    if ((m_a >> u) & 1u) { if (pa < (uint32_t)kLstCap) lst[pa] = (uint16_t)k; pa++; }
+                    if ((m_b >> u) & 1u) { if (pb < (uint32_t)kLstCap) lst[kLstCap - 1 - pb] = (uint16_t)k; pb++; }
                 }
             }
         }
     }
     __syncthreads();
     L3_PH(5);
-    // generic loop: the listed pre-tokens, or all of them again when the list overflowed (then the counters restart)
-    const bool rare_all = (uint32_t)vars[TV_NRARE] > (uint32_t)kRareCap;   // uniform over the workgroup
-    if (rare_all) {
-        __syncthreads();
-        if (tid == 0) vars[TV_NSLOW] = 0;
-        if (tid < kLenClasses) ccnt[tid] = 0;
-        __syncthreads();
-    }
-    {
-        const uint32_t n_iter = rare_all ? n_pre : (uint32_t)vars[TV_NRARE];
+    // Stage 2, the listed pre-tokens, densely packed (one rare pre-token among the 64 of a wave would otherwise drag the
+    // whole wave through the long path).  Front list: second bucket of the short ones; a miss there is a pre-token for
+    // the merge kernel.  Back list (taken by the threads from the back, so that the two run side by side): special
+    // tokens, more than 12 bytes, invalid UTF-8, open ends.  Deferred pre-tokens get their ordinal within the tile (per
+    // length class / in the slow list) here and are noted in `defer`; their records follow once the tile has its room
+    // in the global lists.
+    const uint32_t n_a = (uint32_t)vars[TV_NAB] & 0xFFFFu, n_b = (uint32_t)vars[TV_NAB] >> 16;
+    const bool lst_ovf = n_a + n_b > (uint32_t)kLstCap;   // uniform
+    if (!lst_ovf) {
 #pragma unroll 1
-        for (uint32_t it = tid; it < n_iter; it += kTileThreads) {
-            const uint32_t k = rare_all ? it : (uint32_t)R.rare[it];
-            const int s = R.list[k];
-            const bool special = (R.bm[B_SPS][s >> 6] >> (s & 63)) & 1ull;
-            int e = find_next_bit64(ST, s + 1, eval_hi);
-            if (e < 0 && hard) e = n;
-            const int len = e - s;
-            const bool inval = e >= 0 && any_bit_in(R.bm[B_INV], s, e);
-            int32_t item;
-            if (special) {
-                int canon = 0;
-                special_match(src, s, &canon);
-                item = T.special_id[canon];
+        for (uint32_t it = tid; it < n_a; it += kTileThreads) {
+            const uint32_t k = lst[it];
+            const uint32_t s = R.list[k], len = (uint32_t)R.list[k + 1u] - s;   // 1..12
+            const uint4 m = mk[len];
+            const uint32_t* wp = bw + (s >> 2);
+            const uint32_t sh = s * 8u;
+            const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3];
+            const uint32_t b0 = __funnelshift_r(x0, x1, sh) & m.x, b1 = __funnelshift_r(x1, x2, sh) & m.y, b2 = __funnelshift_r(x2, x3, sh) & m.z;
+            const VocabSlot v = T.vocab_slots[vocab_hash_short_b(b0, b1, b2, len, T.vocab_log2)];
+            if (((v.w[0] ^ b0) | (v.w[1] ^ b1) | (v.w[2] ^ b2) | ((v.w[3] ^ m.w) & ~0x1FFFFu)) == 0) {
+                out0[k] = (int32_t)(v.w[3] & 0x1FFFFu);
             } else {
-                int32_t id = -1;
-                if (e >= 0 && !inval && len <= kMaxTokenBytes) {
-                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
-                    const uint32_t sh = (uint32_t)(s & 3) * 8u;
-                    const uint32_t nw = ((uint32_t)len + 3u) >> 2;
-                    const uint32_t tail = (len & 3) ? (1u << ((len & 3) * 8)) - 1u : 0xFFFFFFFFu;
-                    id = vocab_lookup_words(T, [&](uint32_t i) {
-                        uint32_t x = __funnelshift_r(wp[i], wp[i + 1], sh);
-                        return i + 1 == nw ? x & tail : x;
-                    }, (uint32_t)len);
-                }
-                if (id >= 0) item = id;
-                else if (e >= 0 && !inval && len <= kLaneMax) {
-                    const uint32_t c = len_class((uint32_t)len);
-                    item = -2 - (int32_t)((c << 12) | (uint32_t)atomicAdd(&ccnt[c], 1));
-                }
-                else item = -2 - (int32_t)(kSlowBase + (uint32_t)atomicAdd(&vars[TV_NSLOW], 1));
+                const uint32_t c = len_class(len);
+                const uint32_t ord = (uint32_t)atomicAdd(&ccnt[c], 1);
+                const uint32_t di = (uint32_t)atomicAdd(&vars[TV_NDEF], 1);
+                if (di < (uint32_t)kDeferCap) defer[di] = k | (c << 12) | (ord << 16);
             }
-            if (k < (uint32_t)kResCap) res[k] = item; else out0[k] = item;
+        }
+#pragma unroll 1
+        for (uint32_t it = (uint32_t)(kTileThreads - 1 - tid); it < n_b; it += kTileThreads) {
+            const uint32_t k = lst[kLstCap - 1 - it];
+            const int s = R.list[k];
+            const uint32_t ev = R.list[k + 1u];
+            const int e = ev == kOpenEnd ? -1 : (int)ev;
+            const uint32_t kind = tile_generic_item(T, R, src, bw, s, e, &out0[k]);
+            if (kind) {   // deferred: 1 = short (a lane of the merge kernel), 2 / 3 = slow (3: known to be valid UTF-8)
+                uint32_t d;
+                if (kind == 1u) {
+                    const uint32_t c = len_class((uint32_t)(e - s));
+                    d = k | (c << 12) | ((uint32_t)atomicAdd(&ccnt[c], 1) << 16);
+                } else {
+                    d = 0x80000000u | (kind == 3u ? 0x40000000u : 0u) | k | ((uint32_t)atomicAdd(&vars[TV_NSLOW], 1) << 12);
+                }
+                const uint32_t di = (uint32_t)atomicAdd(&vars[TV_NDEF], 1);
+                if (di < (uint32_t)kDeferCap) defer[di] = d;
+            }
         }
     }
     __syncthreads();
     L3_PH(6);
+    // A tile whose lists overflow (thousands of tiny pre-tokens that are all rare: random bytes) starts over in the
+    // general way: every pre-token through the long path, placeholders with the ordinal inside the tile straight to the
+    // stream, which the last pass below then reads back.
+    const bool general = lst_ovf || (uint32_t)vars[TV_NDEF] > (uint32_t)kDeferCap;   // uniform over the workgroup
+    if (general) {
+        if (tid == 0) vars[TV_NSLOW] = 0;
+        if (tid < kLenClasses) ccnt[tid] = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t k = tid; k < n_pre; k += kTileThreads) {
+            const int s = R.list[k];
+            const uint32_t ev = R.list[k + 1u];
+            const int e = ev == kOpenEnd ? -1 : (int)ev;
+            int32_t item;
+            const uint32_t kind = tile_generic_item(T, R, src, bw, s, e, &item);
+            if (kind == 1u) {
+                const uint32_t c = len_class((uint32_t)(e - s));
+                item = -2 - (int32_t)((c << 12) | (uint32_t)atomicAdd(&ccnt[c], 1));
+            } else if (kind) {
+                item = -2 - (int32_t)(kSlowBase + (uint32_t)atomicAdd(&vars[TV_NSLOW], 1));
+            }
+            out0[k] = item;
+        }
+        __syncthreads();
+    }
     // space in the entry lists: one returning atomic per length class the tile uses (lanes 0..15) and one for the slow
     // list (lane 16), issued here and first needed after the document loop below, so that the round trip overlaps
     const uint32_t sub = (uint32_t)(tile & 3u);
@@ -882,106 +1011,33 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     }
     __syncthreads();
     L3_PH(7);
+    // -- the records of the deferred pre-tokens and their stream items (placeholders that name the global entry)
     {
         const uint32_t s0 = (uint32_t)vars[TV_SLOW0];
-        int32_t* out = W.stream + tile * (uint64_t)kTileCap;
-        // Staged items first, then (rare) those past the staging array, which every thread re-reads from its own
-        // stores.  Keep the two loops written out like this: variants of this pass that used a shared lambda, or one
-        // loop selecting between res[k] and out[k], compiled to code that ran the whole kernel 2x slower on C2.
-        const uint32_t staged = n_pre < (uint32_t)kResCap ? n_pre : (uint32_t)kResCap;
+        if (!general) {
+            const uint32_t n_def = (uint32_t)vars[TV_NDEF];
 #pragma unroll 1
-        for (uint32_t k = tid; k < staged; k += kTileThreads) {
-            int32_t item = res[k];
-            if (item < -1) {  // deferred: global entry index, entry record
-                uint32_t ord = (uint32_t)(-2 - item);
-                const bool slow = ord >= kSlowBase;
-                if (slow) ord -= kSlowBase;
-                const int s = R.list[k];
-                int e = find_next_bit64(ST, s + 1, eval_hi);
-                if (e < 0 && hard) e = n;
-                uint64_t ei;
-                if (slow) {
-                    ei = (uint64_t)s0 + ord;
-                    if (ei < W.slow_cap) {
-                        SlowEntry se;
-                        se.start = g_lo + (uint64_t)s;
-                        se.win0 = 0;
-                        se.len = e < 0 ? 0u : (uint32_t)(e - s);
-                        se.tile = (uint32_t)tile;
-                        se.count = (e >= 0 && !any_bit_in(R.bm[B_INV], s, e)) ? 1u : 0u;   // in: 1 = known to be valid UTF-8
-                        se.pad = 0; se.pool_off = 0;
-                        W.slow[ei] = se;
-                    }
-                    ei += kSlowBase;
-                } else {
-                    const uint32_t c = ord >> 12;
-                    const uint64_t li = (uint64_t)(uint32_t)cm0[c] + (ord & 4095u);
-                    ei = (uint64_t)(c * 4u + sub) * W.miss_shard_cap + li;
-                    if (li < W.miss_shard_cap) {
-                        MissIn mi;
-                        mi.start = g_lo + (uint64_t)s;
-                        mi.tile = (uint32_t)tile;
-                        mi.len = (uint32_t)(e - s);
-                        {   // the first 16 bytes ride along (LDS image, unaligned start), so the merge kernel reads no text
-                            const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
-                            const uint32_t sh = (uint32_t)(s & 3) * 8u;
-                            const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3], x4 = wp[4];
-                            mi.w[0] = __funnelshift_r(x0, x1, sh); mi.w[1] = __funnelshift_r(x1, x2, sh);
-                            mi.w[2] = __funnelshift_r(x2, x3, sh); mi.w[3] = __funnelshift_r(x3, x4, sh);
-                        }
-                        W.miss_in[ei] = mi;
-                    }
-                }
-                item = -2 - (int32_t)(uint32_t)ei;
+            for (uint32_t it = tid; it < n_def; it += kTileThreads) {
+                const uint32_t d = defer[it];
+                const uint32_t k = d & 4095u;
+                const bool slow = (d >> 31) != 0;
+                const uint32_t ord = slow ? (d >> 12) & 4095u : (d >> 16) & 4095u;
+                out0[k] = tile_deferred_record(W, R, bw, cm0, g_lo, tile, sub, s0, k, slow, ord, (d >> 12) & 15u, (d >> 30) & 1u);
             }
-            out[k] = item;
-        }
+        } else {
+            // (every thread re-reads its own stores of the general pass above)
 #pragma unroll 1
-        for (uint32_t k = staged + tid; k < n_pre; k += kTileThreads) {
-            int32_t item = out[k];
-            if (item < -1) {  // deferred: global entry index, entry record
-                uint32_t ord = (uint32_t)(-2 - item);
-                const bool slow = ord >= kSlowBase;
-                if (slow) ord -= kSlowBase;
-                const int s = R.list[k];
-                int e = find_next_bit64(ST, s + 1, eval_hi);
-                if (e < 0 && hard) e = n;
-                uint64_t ei;
-                if (slow) {
-                    ei = (uint64_t)s0 + ord;
-                    if (ei < W.slow_cap) {
-                        SlowEntry se;
-                        se.start = g_lo + (uint64_t)s;
-                        se.win0 = 0;
-                        se.len = e < 0 ? 0u : (uint32_t)(e - s);
-                        se.tile = (uint32_t)tile;
-                        se.count = (e >= 0 && !any_bit_in(R.bm[B_INV], s, e)) ? 1u : 0u;   // in: 1 = known to be valid UTF-8
-                        se.pad = 0; se.pool_off = 0;
-                        W.slow[ei] = se;
-                    }
-                    ei += kSlowBase;
-                } else {
-                    const uint32_t c = ord >> 12;
-                    const uint64_t li = (uint64_t)(uint32_t)cm0[c] + (ord & 4095u);
-                    ei = (uint64_t)(c * 4u + sub) * W.miss_shard_cap + li;
-                    if (li < W.miss_shard_cap) {
-                        MissIn mi;
-                        mi.start = g_lo + (uint64_t)s;
-                        mi.tile = (uint32_t)tile;
-                        mi.len = (uint32_t)(e - s);
-                        {   // the first 16 bytes ride along (LDS image, unaligned start), so the merge kernel reads no text
-                            const uint32_t* wp = reinterpret_cast<const uint32_t*>(R.b) + (s >> 2);
-                            const uint32_t sh = (uint32_t)(s & 3) * 8u;
-                            const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2], x3 = wp[3], x4 = wp[4];
-                            mi.w[0] = __funnelshift_r(x0, x1, sh); mi.w[1] = __funnelshift_r(x1, x2, sh);
-                            mi.w[2] = __funnelshift_r(x2, x3, sh); mi.w[3] = __funnelshift_r(x3, x4, sh);
-                        }
-                        W.miss_in[ei] = mi;
-                    }
+            for (uint32_t k = tid; k < n_pre; k += kTileThreads) {
+                const int32_t item = out0[k];
+                if (item < -1) {
+                    uint32_t ord = (uint32_t)(-2 - item);
+                    const bool slow = ord >= kSlowBase;
+                    if (slow) ord -= kSlowBase;
+                    const uint32_t s = R.list[k], ev = R.list[k + 1u];
+                    const uint32_t valid = (ev != kOpenEnd && !any_bit_in(R.bm[B_INV], (int)s, (int)ev)) ? 1u : 0u;
+                    out0[k] = tile_deferred_record(W, R, bw, cm0, g_lo, tile, sub, s0, k, slow, ord & 4095u, ord >> 12, valid);
                 }
-                item = -2 - (int32_t)(uint32_t)ei;
             }
-            out[k] = item;
         }
     }
     L3_PH(8);
