@@ -40,12 +40,29 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // ---- workgroup primitives (256 threads = 4 waves) --------------------------------------------
+// Data movement between the lanes of a wave by DPP (one VALU operation, no trip through the LDS crossbar as __shfl makes):
+// CTRL 0x111 / 0x112 / 0x114 / 0x118 = row_shr:1/2/4/8 inside rows of 16 lanes, 0x142 / 0x143 = row_bcast:15 / :31 (the last
+// lane of a row to the rows behind it: ROWS 0xA / 0xC), 0x138 / 0x130 = wave_shr:1 / wave_shl:1 (previous / next lane of the
+// wave).  A lane whose source does not exist gets `idle`.  Checked on the device by tools/probes/dpp_shift.hip.  All 64 lanes
+// must be active.
+template <int CTRL, int ROWS = 0xF>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t v, uint32_t idle = 0u) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)idle, (int)v, CTRL, ROWS, 0xF, false);
+}
+// inclusive sum scan over the wave: six v_add_u32_dpp
 __device__ __forceinline__ uint32_t wave_iscan(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane_id() >= d) v += t;
-    }
+    v += dpp_move<0x111>(v);
+    v += dpp_move<0x112>(v);
+    v += dpp_move<0x114>(v);
+    v += dpp_move<0x118>(v);
+    v += dpp_move<0x142, 0xA>(v);
+    v += dpp_move<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_iscan64(unsigned long long v) {
+#define L3_STEP(CTRL, ROWS) v += ((unsigned long long)dpp_move<CTRL, ROWS>((uint32_t)(v >> 32)) << 32) | dpp_move<CTRL, ROWS>((uint32_t)v)
+    L3_STEP(0x111, 0xF); L3_STEP(0x112, 0xF); L3_STEP(0x114, 0xF); L3_STEP(0x118, 0xF); L3_STEP(0x142, 0xA); L3_STEP(0x143, 0xC);
+#undef L3_STEP
     return v;
 }
 // exclusive sum scan over the workgroup; tmp: >= 4 words of LDS.  Contains two barriers.
@@ -242,27 +259,17 @@ __device__ __forceinline__ bool any_bit_in(const u64* bits, int from, int to) { 
     return (bits[w1] & m1) != 0;
 }
 
-__device__ __forceinline__ uint32_t up32(uint32_t v) {  // value of the previous lane (lane 0: 0)
-    uint32_t r = __shfl_up(v, 1, 64);
-    return lane_id() == 0 ? 0u : r;
-}
-__device__ __forceinline__ uint32_t dn32(uint32_t v) {  // value of the next lane (lane 63: 0)
-    uint32_t r = __shfl_down(v, 1, 64);
-    return lane_id() == 63 ? 0u : r;
-}
+__device__ __forceinline__ uint32_t up32(uint32_t v) { return dpp_move<0x138>(v); }  // value of the previous lane (lane 0: 0)
+__device__ __forceinline__ uint32_t dn32(uint32_t v) { return dpp_move<0x130>(v); }  // value of the next lane (lane 63: 0)
+// exclusive segmented scan over the wave; (0, open) is the identity of seg_comb
 __device__ __forceinline__ Seg wave_seg_escan(Seg v) {
     Seg inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        Seg t;
-        t.cnt = __shfl_up(inc.cnt, d, 64);
-        t.open = __shfl_up(inc.open, d, 64);
-        if (lane_id() >= d) inc = seg_comb(t, inc);
-    }
+#define L3_STEP(CTRL, ROWS) { Seg t; t.cnt = dpp_move<CTRL, ROWS>(inc.cnt, 0u); t.open = dpp_move<CTRL, ROWS>(inc.open, 1u); inc = seg_comb(t, inc); }
+    L3_STEP(0x111, 0xF) L3_STEP(0x112, 0xF) L3_STEP(0x114, 0xF) L3_STEP(0x118, 0xF) L3_STEP(0x142, 0xA) L3_STEP(0x143, 0xC)
+#undef L3_STEP
     Seg ex;
-    ex.cnt = __shfl_up(inc.cnt, 1, 64);
-    ex.open = __shfl_up(inc.open, 1, 64);
-    if (lane_id() == 0) { ex.cnt = 0; ex.open = 1; }
+    ex.cnt = dpp_move<0x138>(inc.cnt, 0u);
+    ex.open = dpp_move<0x138>(inc.open, 1u);
     return ex;
 }
 
@@ -441,17 +448,6 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int n, int own_lo, i
     return flags;
 }
 
-// inclusive sum scan over the wave with DPP row shifts and row broadcasts (six v_add_u32_dpp; no LDS crossbar)
-__device__ __forceinline__ uint32_t wave_iscan_dpp(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // One pre-token [s, e) (e < 0: it ends beyond what the halo decides) the long way: special token, whole-string probe of any
 // length (bpe.go:27-33), or deferral.  Returns 0 and the token id in *item, or the kind of deferral (*item untouched): 1 = up
 // to kLaneMax valid bytes (a lane of the merge kernel), 2 = slow, 3 = slow and known to be valid UTF-8.
@@ -593,6 +589,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         }
     }
     const uint32_t d0 = W.tile_doc0[tile];
+    const uint32_t d_end32 = W.tile_doc0[tile + 1];   // (the last tile's entry is n_docs + 1: docs_kernel)
     const uint32_t status_flags = W.status->flags;
 
     // -- clear what is accumulated with atomics
@@ -624,15 +621,13 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     if (tid == 0) *reinterpret_cast<uint4*>(&R.b[kRegion]) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     L3_PH(0);
-    if (tid == 0 && d0 > 0) {
-        uint64_t pos = A.doc_off[d0 - 1];
-        if (pos >= g_lo) atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
-    }
-    for (uint64_t d = (uint64_t)d0 + tid; d <= A.n_docs; d += kTileThreads) {
-        uint64_t pos = A.doc_off[d];
-        if (pos >= g_hi) break;
-        atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
-    }
+    // -- document starts inside the region (one document per thread: d0 - 1 + tid; tiles with more take the loop further
+    //    down): the offsets are requested here and marked behind the classification, which runs while they are in flight;
+    //    the same offsets serve the per-document items at the end of the kernel
+    const uint64_t d_mine = (uint64_t)d0 + tid;
+    uint64_t pos_mine = ~0ull, pos_prev = ~0ull;
+    if (d_mine <= A.n_docs) pos_mine = A.doc_off[d_mine];
+    if (tid == 0 && d0 > 0) pos_prev = A.doc_off[d0 - 1];
     // -- ASCII bytes by table: ctab[v] holds the eight class bits of byte value v spread over four words, two
     //    classes per word at bits 0 and 16 (x: rune start | letter, y: digit | newline, z: blank | other white
     //    space, w: apostrophe | '<'); OR-ing the entry of byte p shifted left by p gathers, for each class, the
@@ -652,6 +647,15 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         m_n = ay & valid; m_nl = (ay >> 16) & valid;
         m_sp = az & valid; m_ws = (az >> 16) & valid;
         m_apos = aw & valid; m_lt = (aw >> 16) & valid;
+    }
+    if (pos_prev != ~0ull && pos_prev >= g_lo) atomicOr(&R.bm[B_DS][(pos_prev - g_lo) >> 6], 1ull << ((pos_prev - g_lo) & 63));
+    if (pos_mine < g_hi) {
+        atomicOr(&R.bm[B_DS][(pos_mine - g_lo) >> 6], 1ull << ((pos_mine - g_lo) & 63));
+        for (uint64_t d = d_mine + kTileThreads; d <= A.n_docs; d += kTileThreads) {   // (more than 256 documents start in the region)
+            const uint64_t pos = A.doc_off[d];
+            if (pos >= g_hi) break;
+            atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
+        }
     }
     __syncthreads();
     L3_PH(1);
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             }
             // one scan per wave for both lists (the two counts packed in one word), one LDS atomic per wave
             const uint32_t cnt_a = (uint32_t)__popc(m_a), cnt_b = (uint32_t)__popc(m_b);
-            const uint32_t inc = wave_iscan_dpp(cnt_a | (cnt_b << 16));
+            const uint32_t inc = wave_iscan(cnt_a | (cnt_b << 16));
             const uint32_t tot = __builtin_amdgcn_readlane(inc, 63);
             if (tot) {   // uniform over the wave
                 uint32_t basep = 0;
@@ -985,12 +989,12 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         // end of a pre-token that runs past this tile's look-ahead, and whether its symbols can differ from its bytes
         W.tile_first[tile] = (n_pre ? (uint32_t)(R.list[0] - own_lo) : kNoFirst) | (vars[TV_OWNINV] ? kFirstInv : 0u);
     }
-    // -- stream index of the first item of every document that starts in this tile
+    // -- stream index of the first item of every document that starts in this tile (the first 256 from the offsets loaded
+    //    at the start of the kernel)
     {
-        const bool last_tile = tile + 1 == gridDim.x;
-        const uint64_t d_end = last_tile ? A.n_docs + 1 : (uint64_t)W.tile_doc0[tile + 1];
-        for (uint64_t d = (uint64_t)d0 + tid; d < d_end; d += kTileThreads) {
-            const int pos = (int)(A.doc_off[d] - g_lo);
+        const uint64_t d_end = d_end32;
+        for (uint64_t d = d_mine; d < d_end; d += kTileThreads) {
+            const int pos = (int)((d == d_mine ? pos_mine : A.doc_off[d]) - g_lo);
             uint32_t item;
             if (pos >= own_hi) item = n_pre;
             else {
@@ -2481,12 +2485,7 @@ __device__ __forceinline__ int32_t deferred_token(const Workspace& W, uint64_t l
 }
 // exclusive scan of two 32-bit counters packed in one 64-bit word; tmp: >= 4 words.  Two barriers.
 __device__ __forceinline__ unsigned long long block_escan64(unsigned long long v, unsigned long long* tmp, unsigned long long* total) {
-    unsigned long long inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned long long o = __shfl_up(inc, d, 64);
-        if (lane_id() >= d) inc += o;
-    }
+    const unsigned long long inc = wave_iscan64(v);
     if (lane_id() == 63) tmp[wave_id()] = inc;
     __syncthreads();
     unsigned long long base = 0, tot = 0;
