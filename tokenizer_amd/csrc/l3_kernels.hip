@@ -212,12 +212,15 @@ constexpr uint32_t kOpenEnd = 0xFFFFu;   // TileLds::list[n_pre]: the last own p
 constexpr int kLenClasses = 16;
 static_assert(kLenClasses * 4 == kMissShards, "shard = length class * 4 + (tile & 3)");
 __device__ __forceinline__ uint32_t len_class(uint32_t len) { return (len < (uint32_t)kLenClasses ? len : (uint32_t)kLenClasses) - 1u; }
+#ifndef L3_LIST_CAP
+#define L3_LIST_CAP (kTile + 2)
+#endif
 struct TileLds {
     uint8_t b[kRegion + 16];
     u64 bm[B_COUNT][kWords + 2];
     union {
-        uint16_t list[kTile + 2];  // compacted own pre-token starts (region-local offsets) + the end of the last one
-        uint4 ctab[256];       // before that: class bits of every byte value, see the classification step
+        uint16_t list[L3_LIST_CAP];  // compacted own pre-token starts (region-local offsets) + the end of the last one
+        uint2 ctab[256];       // before that: class bits of every byte value, see the classification step
     };
     uint16_t wpre[kWords + 1]; // own pre-token starts before each mask word
 };
@@ -517,6 +520,30 @@ __device__ __forceinline__ int32_t tile_deferred_record(const Workspace& W, cons
     return -2 - (int32_t)(uint32_t)ei;
 }
 
+// Class bits of the 256 byte values for the table step of the tile kernel (state_machine.go:310-320 for ASCII: letters, Nd
+// digits, unicode.IsSpace), one class per byte of two words: x = ASCII | letter << 8 | digit << 16 | newline << 24,
+// y = blank | other white space << 8 | apostrophe << 16 | '<' << 24.  Bytes >= 0x80 have an all-zero entry.  A constant of
+// the code object: every tile copies it into LDS with one coalesced load.
+struct AsciiCls { uint32_t v[512]; };
+constexpr AsciiCls make_ascii_cls() {
+    AsciiCls t{};
+    for (uint32_t v = 0; v < 256; v++) {
+        const uint32_t f = v | 0x20u;
+        const uint32_t asc = v < 0x80u ? 1u : 0u;
+        const uint32_t cl = (f >= 'a' && f <= 'z') ? asc : 0u;
+        const uint32_t cn = (v >= '0' && v <= '9') ? 1u : 0u;
+        const uint32_t cnl = (v == '\n' || v == '\r') ? 1u : 0u;
+        const uint32_t csp = v == ' ' ? 1u : 0u;
+        const uint32_t cws = (v >= 9u && v <= 13u && !cnl) ? 1u : 0u;
+        const uint32_t cap = v == '\'' ? 1u : 0u;
+        const uint32_t clt = v == '<' ? 1u : 0u;
+        t.v[2 * v] = asc | (cl << 8) | (cn << 16) | (cnl << 24);
+        t.v[2 * v + 1] = csp | (cws << 8) | (cap << 16) | (clt << 24);
+    }
+    return t;
+}
+__device__ const AsciiCls g_ascii_cls = make_ascii_cls();
+
 #ifndef L3_TILE_OCC
 #define L3_TILE_OCC 7
 #endif
@@ -561,6 +588,10 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     __shared__ int vars[TV_COUNT];
     __shared__ int ccnt[kLenClasses], cm0[kLenClasses];   // short deferred pre-tokens per length class; their first entry
     __shared__ uint4 mk[kVocabInline + 1];
+#ifdef L3_LDS_PAD   // occupancy experiments (tools/build_kvariant.sh): extra LDS per workgroup
+    __shared__ uint32_t lds_pad[L3_LDS_PAD / 4];
+    asm volatile("" :: "v"(&lds_pad[threadIdx.x]) : "memory");
+#endif
 
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     L3_PH_INIT();
@@ -574,23 +605,20 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     const bool hard = g_hi == A.n_bytes;
     const int eval_hi = hard ? n : n - kEvalSlack;
 
-    // -- the three loads a tile starts with are requested together (its own 16 bytes of text, its first document, the
-    //    status word); the LDS set-up below runs while they are in flight
+    // -- the loads a tile starts with are requested together (its own 16 bytes of text, the documents of the tile, the
+    //    status word, the class table entry); the LDS set-up below runs while they are in flight.  Text: g_lo and c0 are
+    //    multiples of 16, so with a 16-byte aligned batch every thread makes ONE aligned 16-byte load, also where fewer than
+    //    16 bytes remain (an aligned 16-byte piece lies inside one page: the load cannot fault; the surplus is masked below).
     const int c0 = tid * 16;            // region bytes [c0, c0 + 16) are classified by this thread
     const bool cls_thread = tid < kRegion / 16;
-    uint32_t xw[4] = {0, 0, 0, 0};
-    if (cls_thread && c0 < n) {
-        const uint8_t* srcp = A.text + g_lo + c0;
-        if (c0 + 16 <= n && (((uintptr_t)srcp) & 15u) == 0) {
-            const uint4 v = *reinterpret_cast<const uint4*>(srcp);
-            xw[0] = v.x; xw[1] = v.y; xw[2] = v.z; xw[3] = v.w;
-        } else {
-            for (int k = 0; k < 16 && c0 + k < n; k++) xw[k >> 2] |= (uint32_t)srcp[k] << ((k & 3) * 8);
-        }
-    }
+    const bool cls_in = cls_thread && c0 < n;
+    const bool text_al = (((uintptr_t)A.text) & 15u) == 0;   // uniform
+    uint4 xv = make_uint4(0, 0, 0, 0);
+    if (cls_in && text_al) xv = *reinterpret_cast<const uint4*>(A.text + g_lo + c0);
     const uint32_t d0 = W.tile_doc0[tile];
     const uint32_t d_end32 = W.tile_doc0[tile + 1];   // (the last tile's entry is n_docs + 1: docs_kernel)
     const uint32_t status_flags = W.status->flags;
+    const uint2 cls_entry = reinterpret_cast<const uint2*>(g_ascii_cls.v)[tid];   // (256 threads, 256 entries)
 
     // -- clear what is accumulated with atomics
     for (int i = tid; i < kWords + 2; i += kTileThreads) {
@@ -603,20 +631,24 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                              l >= 12u ? 0xFFFFFFFFu : (l > 8u ? (1u << (8u * (l - 8u))) - 1u : 0u), l << 17);
     }
     if (tid < kLenClasses) ccnt[tid] = 0;
-    {   // class table entry of byte value `tid` (state_machine.go:310-320 for ASCII: letters, Nd digits, unicode.IsSpace)
-        const uint32_t v = (uint32_t)tid;
-        const uint32_t f = v | 0x20u;
-        const uint32_t asc = v < 0x80u ? 1u : 0u;
-        const uint32_t cl = (f >= 'a' && f <= 'z') ? asc : 0u;
-        const uint32_t cn = (v >= '0' && v <= '9') ? 1u : 0u;
-        const uint32_t cnl = (v == '\n' || v == '\r') ? 1u : 0u;
-        const uint32_t csp = v == ' ' ? 1u : 0u;
-        const uint32_t cws = (v >= 9u && v <= 13u && !cnl) ? 1u : 0u;
-        const uint32_t cap = v == '\'' ? 1u : 0u;
-        const uint32_t clt = v == '<' ? 1u : 0u;
-        R.ctab[tid] = make_uint4(asc | (cl << 16), cn | (cnl << 16), csp | (cws << 16), cap | (clt << 16));
-    }
+    // (the loaded values are first looked at here, behind the set-up)
+    asm volatile("" : "+v"(xv.x), "+v"(xv.y), "+v"(xv.z), "+v"(xv.w));
+    R.ctab[tid] = cls_entry;
     if (status_flags & kBadOffsets) return;   // (uniform; tile_doc0 is only trustworthy without it)
+    uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (cls_in && (!text_al || c0 + 16 > n)) {   // rare: a batch that is not 16-byte aligned, the last bytes of the text
+        if (!text_al) {
+            const uint8_t* srcp = A.text + g_lo + c0;
+            for (int k = 0; k < 16 && c0 + k < n; k++) xw[k >> 2] |= (uint32_t)srcp[k] << ((k & 3) * 8);
+        } else {
+            const int nb = n - c0;   // 1..15 bytes are text
+            for (int j = 0; j < 4; j++) {
+                const int keep = nb - 4 * j;
+                if (keep <= 0) xw[j] = 0;
+                else if (keep < 4) xw[j] &= (1u << (8 * keep)) - 1u;
+            }
+        }
+    }
     if (cls_thread) *reinterpret_cast<uint4*>(&R.b[c0]) = make_uint4(xw[0], xw[1], xw[2], xw[3]);
     if (tid == 0) *reinterpret_cast<uint4*>(&R.b[kRegion]) = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -628,21 +660,25 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     uint64_t pos_mine = ~0ull, pos_prev = ~0ull;
     if (d_mine <= A.n_docs) pos_mine = A.doc_off[d_mine];
     if (tid == 0 && d0 > 0) pos_prev = A.doc_off[d0 - 1];
-    // -- ASCII bytes by table: ctab[v] holds the eight class bits of byte value v spread over four words, two
-    //    classes per word at bits 0 and 16 (x: rune start | letter, y: digit | newline, z: blank | other white
-    //    space, w: apostrophe | '<'); OR-ing the entry of byte p shifted left by p gathers, for each class, the
-    //    16-bit mask of this thread's bytes.  One 16-byte LDS read and four shift-ORs per byte (the arithmetic
-    //    version of this step took 29 ALU operations per byte).  Bytes >= 0x80 have an all-zero entry.
+    // -- ASCII bytes by table: ctab[v] holds the eight class bits of byte value v, one per byte of two words (x: rune
+    //    start, letter, digit, newline; y: blank, other white space, apostrophe, '<').  OR-ing the entry of byte p shifted
+    //    left by p mod 8 gathers, for each class, the 8-bit mask of the thread's bytes 0..7 and of its bytes 8..15: one
+    //    8-byte LDS read and two shift-ORs per byte (the arithmetic version of this step took 29 ALU operations per byte),
+    //    then four byte permutes put the halves together, two classes per word at bits 0 and 16.  Bytes >= 0x80 have an
+    //    all-zero entry.
     uint32_t m_rs = 0, m_l = 0, m_n = 0, m_nl = 0, m_sp = 0, m_ws = 0, m_apos = 0, m_lt = 0;
     if (cls_thread) {
         const uint32_t valid = c0 + 16 <= n ? 0xFFFFu : (c0 < n ? (1u << (n - c0)) - 1u : 0u);
-        uint32_t ax = 0, ay = 0, az = 0, aw = 0;
+        uint32_t lx = 0, ly = 0, hx = 0, hy = 0;
 #pragma unroll
-        for (int p = 0; p < 16; p++) {
-            const uint32_t v = (xw[p >> 2] >> ((p & 3) * 8)) & 0xFFu;
-            const uint4 e = R.ctab[v];
-            ax |= e.x << p; ay |= e.y << p; az |= e.z << p; aw |= e.w << p;
+        for (int p = 0; p < 8; p++) {
+            const uint2 e = R.ctab[(xw[p >> 2] >> ((p & 3) * 8)) & 0xFFu];
+            lx |= e.x << p; ly |= e.y << p;
+            const uint2 f = R.ctab[(xw[2 + (p >> 2)] >> ((p & 3) * 8)) & 0xFFu];
+            hx |= f.x << p; hy |= f.y << p;
         }
+        const uint32_t ax = __builtin_amdgcn_perm(hx, lx, 0x05010400u), ay = __builtin_amdgcn_perm(hx, lx, 0x07030602u);
+        const uint32_t az = __builtin_amdgcn_perm(hy, ly, 0x05010400u), aw = __builtin_amdgcn_perm(hy, ly, 0x07030602u);
         m_rs = ax & valid; m_l = (ax >> 16) & valid;
         m_n = ay & valid; m_nl = (ay >> 16) & valid;
         m_sp = az & valid; m_ws = (az >> 16) & valid;
