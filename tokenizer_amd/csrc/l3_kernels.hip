@@ -1119,10 +1119,13 @@ __device__ __forceinline__ void lane_merge(const Tables& T, uint32_t* sy, uint32
         uint32_t idr = 0, idl = 0;
         if (r != kNone) { const uint32_t wr = sy[r]; idr = wr & 0x1FFFFu; sy[r] = (wr & 0x00FFFFFFu) | (bp << 24); }
         if (l != kNone) idl = sy[l] & 0x1FFFFu;
-        uint32_t pa = kNoPrio, pb = kNoPrio;
-        if (r != kNone && l != kNone) pair_prio2(T, m, idr, idl, m, &pa, &pb);
-        else if (r != kNone) pa = pair_prio(T, m, idr);
-        else if (l != kNone) pb = pair_prio(T, idl, m);
+        // both new pairs are probed whatever the neighbours are (a missing neighbour probes the pair (0, 0) and the answer is
+        // dropped): ONE path for all lanes, four loads in flight, one memory round trip per merge.  With a branch per case the
+        // lanes of a wave took up to three round trips in turn.
+        uint32_t pa, pb;
+        pair_prio2(T, r != kNone ? m : 0u, idr, idl, l != kNone ? m : 0u, &pa, &pb);
+        if (r == kNone) pa = kNoPrio;
+        if (l == kNone) pb = kNoPrio;
         pq[bp] = pa == kNoPrio ? 0xFFFFFFFFu : (pa << 7) | bp;
         if (l != kNone) pq[l] = pb == kNoPrio ? 0xFFFFFFFFu : (pb << 7) | l;
     }
@@ -2536,33 +2539,23 @@ __device__ __forceinline__ unsigned long long block_escan64(unsigned long long v
     return base + inc - v;
 }
 // ---- final scatter, fast path ---------------------------------------------------------------------------
-// One workgroup per tile, four consecutive items per thread.  The tile's tokens, BOS and EOS are assembled in an
-// LDS staging buffer at their position relative to the tile's first output slot and leave as one contiguous,
-// coalesced run.  Document starts are a bit per item (tiles with several documents on one item go to the
-// generic kernel, as do tiles with more tokens than the staging buffer holds).
-constexpr int kStage = 3072;
-#ifndef L3_EMIT_PER
-#define L3_EMIT_PER 4
-#endif
-constexpr int kEmitItemsPer = L3_EMIT_PER;   // 2 or 4
-constexpr int kEmitRound = kTileThreads * kEmitItemsPer;
-constexpr int kDmaskWords = (kTileCap + 64) / 64 + 1;
-static_assert(kDmaskWords <= 64, "one wave scans the document-start words");
+// One WAVE per tile, no LDS, no workgroup barrier: the 64 lanes take 64 consecutive items of the tile's stream at a time
+// (four such steps are in flight together), so the tokens of a step leave as one coalesced store wherever every item is one
+// token, and the prefix sums a step needs are wave scans by DPP.  The document starts of the tile (a bit per item) live in
+// registers: lane w holds word w of the bit map and the number of starts before it.  Tiles with several documents on one
+// item (empty documents) or more than kEmitDocs documents go to the generic kernel.
+constexpr int kEmitDocs = 256;
+constexpr int kEmitSteps = 4;                       // steps of 64 items in flight
+constexpr int kEmitRound = 64 * kEmitSteps;
+static_assert((kTileCap + 1 + 63) / 64 <= 64, "one lane per word of the document-start bit map");
 #ifndef L3_EMIT_OCC
-#define L3_EMIT_OCC 6
+#define L3_EMIT_OCC 8
 #endif
-__global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspace W, EncodeArgs A) {
-    __shared__ int32_t stg[kStage];
-    __shared__ unsigned long long dmask[kDmaskWords];
-    __shared__ uint32_t wordpre[kDmaskWords];
-    __shared__ unsigned long long tmp64[8];
-    __shared__ unsigned long long q_rel[kEmitQueue];
-    __shared__ int32_t q_item[kEmitQueue];
-    __shared__ uint32_t q_n, s_generic;
-
+__global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspace W, EncodeArgs A, uint32_t n_tiles) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint64_t tile = (uint64_t)blockIdx.x * (kTileThreads / 64) + (uint32_t)wave_id();
+    if (tile >= n_tiles) return;   // (whole waves: nothing below synchronises across waves)
     // every parameter load is requested before the first branch: one memory round trip, not three
-    const int tid = threadIdx.x;
-    const uint64_t tile = blockIdx.x;
     const TileRec rec = W.tile_rec[tile];
     const unsigned long long blk_base = W.tile_base[tile / kScanBlock];
     const uint32_t fl = W.status->flags;
@@ -2570,128 +2563,101 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
     if (fl & (kFatalFlags | kRetryFlags | kGiantPending | kSeqPending)) return;
     if (total_tokens > A.out_cap) return;
     const uint32_t n_items = rec.n_items;
-    const uint64_t n_tok = (uint64_t)n_items + rec.n_extra;
     const uint64_t d_lo = rec.d_lo, d_hi = rec.d_hi;
     const uint32_t bos = A.flags & 1u, eos = (A.flags >> 1) & 1u, be = bos + eos;
     const unsigned long long base = blk_base + rec.pre;
     const int32_t* in = W.stream + tile * (uint64_t)kTileCap;
-    const uint64_t n_tdocs = d_hi - d_lo;
-    if (n_tok + (n_tdocs + 1) * be > (uint64_t)kStage || n_tdocs > (uint64_t)n_items + 1) {
-        if (tid == 0) { W.tile_flag[tile] = 1; atomicAdd(&W.status->generic_tiles, 1u); }
+    const uint32_t n_tdocs = (uint32_t)(d_hi - d_lo);
+    bool generic = n_tdocs > n_items + 1u || n_tdocs > (uint32_t)kEmitDocs;
+    // -- document starts: bit `it` of the map for every document whose first item is `it`
+    u64 dm = 0;         // lane w: word w
+    if (!generic) {
+        for (uint32_t d0 = 0; d0 < n_tdocs; d0 += 64) {
+            const uint32_t nd = n_tdocs - d0 < 64u ? n_tdocs - d0 : 64u;
+            const uint32_t it_v = lane < nd ? W.doc_item[d_lo + d0 + lane] : 0u;
+            for (uint32_t k = 0; k < nd; k++) {   // (uniform)
+                const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)it_v, (int)k);
+                if (lane == (it >> 6)) dm |= 1ull << (it & 63u);
+            }
+        }
+    }
+    const uint32_t dcnt = (uint32_t)__popcll(dm);
+    const uint32_t dinc = wave_iscan(dcnt);
+    const uint32_t dpre = dinc - dcnt;   // lane w: document starts before word w
+    if ((uint32_t)__builtin_amdgcn_readlane((int)dinc, 63) != n_tdocs) generic = true;   // two documents start at one item
+    if (generic) {   // (uniform over the wave)
+        if (lane == 0) { W.tile_flag[tile] = 1; atomicAdd(&W.status->generic_tiles, 1u); }
         return;
     }
-    if (tid < kDmaskWords) dmask[tid] = 0;
-    if (tid == 0) { q_n = 0; s_generic = 0; }
-    __syncthreads();
-    for (uint64_t d = d_lo + tid; d < d_hi; d += kTileThreads) {
-        const uint32_t it = W.doc_item[d];
-        atomicOr(&dmask[it >> 6], 1ull << (it & 63));
-    }
-    __syncthreads();
-    if (tid < 64) {
-        const uint32_t c = tid < kDmaskWords ? (uint32_t)__popcll(dmask[tid]) : 0u;
-        const uint32_t inc = wave_iscan(c);
-        if (tid < kDmaskWords) wordpre[tid] = inc - c;
-        if (tid == 63 && inc != (uint32_t)n_tdocs) s_generic = 1;   // two documents start at one item
-    }
-    __syncthreads();
-    if (s_generic) {
-        if (tid == 0) { W.tile_flag[tile] = 1; atomicAdd(&W.status->generic_tiles, 1u); }
-        return;
-    }
-    if (tid == 0) W.tile_flag[tile] = 0;
-    // output slot of staging index 0 (may be -1 for the first tile; nothing is staged below rel_lo then)
+    if (lane == 0) W.tile_flag[tile] = 0;
+    // output slot of relative position 0 (may be -1 for the first tile; nothing is written below position 0 then)
     const long long o_base = (long long)base + (long long)d_lo * be - be + bos;
+    int32_t* out = A.out_tok;
 
-    unsigned long long carry = 0;  // low 32: tokens, high 32: documents started
-    const uint32_t rounds = (n_items + 1 + kEmitRound - 1) / kEmitRound;
+    uint32_t carry = 0;   // tokens of the items before the current step (uniform)
+    const uint32_t rounds = (n_items + 1u + (uint32_t)kEmitRound - 1u) / (uint32_t)kEmitRound;
 #pragma unroll 1
     for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t i0 = r * kEmitRound + (uint32_t)tid * kEmitItemsPer;
-        int32_t item[kEmitItemsPer];
-        if (i0 + kEmitItemsPer <= n_items) {
-            if constexpr (kEmitItemsPer == 4) {
-                const int4 v = *reinterpret_cast<const int4*>(in + i0);
-                item[0] = v.x; item[1] = v.y; item[2] = v.z; item[kEmitItemsPer - 1] = v.w;
-            } else {
-                const int2 v = *reinterpret_cast<const int2*>(in + i0);
-                item[0] = v.x; item[kEmitItemsPer - 1] = v.y;
-            }
-        } else {
+        int32_t item[kEmitSteps];
+        uint32_t cnt[kEmitSteps];
+        uint64_t loc[kEmitSteps];
+        bool inl[kEmitSteps];
 #pragma unroll
-            for (int j = 0; j < kEmitItemsPer; j++) item[j] = i0 + j < n_items ? in[i0 + j] : kDead;
+        for (int s = 0; s < kEmitSteps; s++) {
+            const uint32_t i = r * (uint32_t)kEmitRound + (uint32_t)s * 64u + lane;
+            item[s] = i < n_items ? in[i] : kDead;
         }
-        uint32_t cnt[kEmitItemsPer];
-        uint64_t poff[kEmitItemsPer];
-        bool inl[kEmitItemsPer];
 #pragma unroll
-        for (int j = 0; j < kEmitItemsPer; j++) {
-            cnt[j] = item[j] >= 0 ? 1u : 0u;
-            poff[j] = 0;
-            inl[j] = false;
-            if (item[j] < kDead) deferred_result(W, item[j], &poff[j], &cnt[j], &inl[j]);
+        for (int s = 0; s < kEmitSteps; s++) {
+            cnt[s] = item[s] >= 0 ? 1u : 0u;
+            loc[s] = 0;
+            inl[s] = false;
+            if (item[s] < kDead) deferred_result(W, item[s], &loc[s], &cnt[s], &inl[s]);
         }
-        const uint32_t dbits = i0 <= n_items ? (uint32_t)(dmask[i0 >> 6] >> (i0 & 63)) & ((1u << kEmitItemsPer) - 1u) : 0u;  // i0 % kEmitItemsPer == 0: one word
-        const uint32_t dprev = i0 <= n_items ? wordpre[i0 >> 6] + (uint32_t)__popcll(dmask[i0 >> 6] & ((1ull << (i0 & 63)) - 1ull)) : 0u;
-        uint32_t csum = 0;
 #pragma unroll
-        for (int j = 0; j < kEmitItemsPer; j++) csum += cnt[j];
-        unsigned long long tot;
-        const unsigned long long ex = carry + block_escan64((unsigned long long)csum, tmp64, &tot);
-        carry += tot;
-        uint32_t tp = (uint32_t)ex;
-#pragma unroll
-        for (int j = 0; j < kEmitItemsPer; j++) {
-            const uint32_t i = i0 + j;
-            const uint32_t dp = dprev + (uint32_t)__popc(dbits & ((2u << j) - 1u));  // documents that start at or before item i
+        for (int s = 0; s < kEmitSteps; s++) {
+            const uint32_t w = r * (uint32_t)kEmitSteps + (uint32_t)s;      // word of the bit map this step looks at (uniform)
+            const uint32_t i = w * 64u + lane;
+            const uint32_t inc = wave_iscan(cnt[s]);
+            const uint32_t tp = carry + inc - cnt[s];                         // tokens of the tile before item i
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dm, (int)(w & 63u));
+            const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dm >> 32), (int)(w & 63u));
+            const uint32_t w_pre = (uint32_t)__builtin_amdgcn_readlane((int)dpre, (int)(w & 63u));
+            const u64 word = ((u64)w_hi << 32) | w_lo;
+            const bool starts = (word >> lane) & 1ull;
+            const uint32_t dp = w_pre + (uint32_t)__popcll(word & ((2ull << lane) - 1ull));   // documents that start at or before item i
             const uint32_t rel = tp + dp * be;
-            if (i <= n_items && ((dbits >> j) & 1u)) {   // a document starts here (tokenizer.go:225-229,258-262)
+            if (starts && i <= n_items) {   // a document starts here (tokenizer.go:225-229,258-262)
                 const uint64_t d = d_lo + dp - 1;
                 A.out_off[d] = base + tp + d * be;
-                if (bos && d < A.n_docs) stg[rel - bos] = W.bos_id;
-                if (eos && d > 0) stg[rel - bos - 1] = W.eos_id;
+                if (bos && d < A.n_docs) out[o_base + (long long)rel - bos] = W.bos_id;
+                if (eos && d > 0) out[o_base + (long long)rel - bos - 1] = W.eos_id;
             }
             if (i < n_items) {
-                if (item[j] >= 0) {
-                    stg[rel] = item[j];
-                } else if (inl[j]) {   // up to three tokens inside the result word: straight-line stores
-                    stg[rel] = (int32_t)(poff[j] & 0x1FFFFu);
-                    if (cnt[j] > 1) stg[rel + 1] = (int32_t)((poff[j] >> 17) & 0x1FFFFu);
-                    if (cnt[j] > 2) stg[rel + 2] = (int32_t)((poff[j] >> 34) & 0x1FFFFu);
-                } else if (cnt[j] <= 64) {
-                    for (uint32_t k = 0; k < cnt[j]; k++) stg[rel + k] = W.pool[poff[j] + k];
-                } else {
-                    const uint32_t qi = atomicAdd(&q_n, 1u);
-                    if (qi < kEmitQueue) { q_rel[qi] = rel; q_item[qi] = item[j]; }
+                if (item[s] >= 0) {
+                    out[o_base + (long long)rel] = item[s];
+                } else if (inl[s]) {   // up to three tokens inside the result word: straight-line stores
+                    out[o_base + (long long)rel] = (int32_t)(loc[s] & 0x1FFFFu);
+                    if (cnt[s] > 1) out[o_base + (long long)rel + 1] = (int32_t)((loc[s] >> 17) & 0x1FFFFu);
+                    if (cnt[s] > 2) out[o_base + (long long)rel + 2] = (int32_t)((loc[s] >> 34) & 0x1FFFFu);
                 }
             }
-            tp += cnt[j];
+            // runs of tokens from the pool: copied by the whole wave, one run after the other
+            u64 runs = __ballot(i < n_items && item[s] < kDead && !inl[s] && cnt[s] > 0);
+            while (runs) {   // (uniform)
+                const int b = __builtin_ctzll(runs);
+                runs &= runs - 1ull;
+                const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt[s], b);
+                const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)rel, b);
+                const uint64_t po = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(loc[s] >> 32), b) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)loc[s], b);
+                const int32_t* src = W.pool + po;
+                int32_t* dst = out + (o_base + (long long)rl);
+                for (uint32_t k = lane; k < cn; k += 64) dst[k] = src[k];
+            }
         }
     }
-    __syncthreads();
-    // long runs of tokens from the pool: copied by the whole workgroup.  (A tile that reaches this point stages at most
-    // kStage tokens -- tiles with more were flagged for the generic kernel above --, so it holds fewer than
-    // kStage / 65 < kEmitQueue pre-tokens of more than 64 tokens.)
-    const uint32_t qn = q_n < kEmitQueue ? q_n : kEmitQueue;
-    for (uint32_t qi = 0; qi < qn; qi++) {
-        uint64_t po; uint32_t cn; bool il;
-        deferred_result(W, q_item[qi], &po, &cn, &il);
-        const uint32_t rel = (uint32_t)q_rel[qi];
-        for (uint32_t k = tid; k < cn; k += kTileThreads) stg[rel + k] = W.pool[po + k];
-    }
-    if (qn) __syncthreads();
-    // what this tile staged: [rel_lo, rel_hi)
-    const bool starts0 = (dmask[0] & 1ull) != 0;
-    const uint32_t rel_lo = (starts0 && eos && d_lo == 0) ? 1u : 0u;
-    const bool slot_doc = (dmask[n_items >> 6] >> (n_items & 63)) & 1ull;   // a document starts after the last item
-    const uint32_t d_in = (uint32_t)n_tdocs - (slot_doc ? 1u : 0u);
-    uint32_t rel_hi = (uint32_t)n_tok + d_in * be;
-    if (slot_doc) {
-        const uint64_t d = d_hi - 1;
-        if (bos && d < A.n_docs) rel_hi = (uint32_t)n_tok + d_in * be + eos + 1u;
-        else if (eos && d > 0) rel_hi += 1u;
-    }
-    for (uint32_t r = rel_lo + (uint32_t)tid; r < rel_hi; r += kTileThreads) A.out_tok[o_base + (long long)r] = stg[r];
 }
 
 // Tiles the fast kernel leaves (W.tile_flag): several documents starting at one item (empty documents), or more tokens
@@ -3017,7 +2983,8 @@ hipError_t launch_slow_second_pass(const Tables& T, const Workspace& W, const En
 hipError_t launch_encode_tail(const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
     hipError_t e_ = launch_totals_scan(W, A, stream);
     if (e_ != hipSuccess) return e_;
-    hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)num_tiles(A.n_bytes)), dim3(kTileThreads), 0, stream, W, A);
+    hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)((num_tiles(A.n_bytes) + kTileThreads / 64 - 1) / (kTileThreads / 64))), dim3(kTileThreads), 0, stream, W, A,
+                       (uint32_t)num_tiles(A.n_bytes));
     L3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3062,7 +3029,7 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         if (e2_ != hipSuccess) return e2_;
         L3_EV(kEvScan);
     }
-    hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)n_tiles), dim3(kTileThreads), 0, stream, W, A);
+    hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)((n_tiles + kTileThreads / 64 - 1) / (kTileThreads / 64))), dim3(kTileThreads), 0, stream, W, A, (uint32_t)n_tiles);
     L3_LAUNCH_CHECK();
     if (emit_only) {   // the re-run after the caller enlarged its buffer: the flags of the first run are gone
         hipError_t e_ = launch_emit_generic(W, A, stream);
