@@ -186,3 +186,41 @@ def test_submit_wait_pipeline(ctx, oracle):
                                     dev[1][2].data_ptr(), dev[1][4], dev[1][3].data_ptr(), None)
     assert rc == capi.L3_OK
     check(0, t)
+
+
+@pytest.mark.gpu
+def test_submit_alternating_streams(ctx, oracle):
+    """Batches submitted in turn on the context's own stream (stream = NULL) and on caller streams while the ones before
+    are still pending: they share the workspace and the status word, so each must start behind the one before it whatever
+    the streams are (the context orders them by an event recorded behind every batch).  Many rounds, outputs against the
+    oracle."""
+    import torch
+    from tokenizer_amd import capi
+    n_b = 4
+    batches = [corpora.english(8192 + 1024 * b, DOC, first_doc=123000 * (b + 1)) for b in range(n_b)]
+    exp = [oracle.encode_batch(t, o, True, True, threads=8) for t, o in batches]
+    dev = []
+    for text, off in batches:
+        cap = int(text.size) // 2 + 2 * (off.size - 1) + 16
+        dev.append((torch.from_numpy(np.ascontiguousarray(text)).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(),
+                    torch.full((cap,), -3, dtype=torch.int32, device="cuda"), torch.full((off.size,), -3, dtype=torch.int64, device="cuda"), cap))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    streams = [None, s1.cuda_stream, None, s2.cuda_stream, s1.cuda_stream, None, s2.cuda_stream, s2.cuda_stream]
+    for rnd in range(12):
+        for g in range(0, len(streams), n_b):
+            tickets = []
+            for b in range(n_b):
+                d_text, d_off, d_out, d_oo, cap = dev[b]
+                d_out.fill_(-3)
+                torch.cuda.synchronize()
+                rc, t = ctx.encode_submit(d_text.data_ptr(), int(batches[b][0].size), d_off.data_ptr(), batches[b][1].size - 1, 3,
+                                          d_out.data_ptr(), cap, d_oo.data_ptr(), streams[(g + b + rnd) % len(streams)])
+                assert rc == capi.L3_OK, ctx._err(rc)
+                tickets.append(t)
+            for b in range(n_b):
+                rc, n = ctx.encode_wait(tickets[b])
+                assert rc == capi.L3_OK, ctx._err(rc)
+                assert n == exp[b][0].size
+                assert np.array_equal(dev[b][2][:n].cpu().numpy(), exp[b][0]), (rnd, g, b)
+                assert np.array_equal(dev[b][3].cpu().numpy().astype(np.uint64), exp[b][1])

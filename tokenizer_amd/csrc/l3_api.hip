@@ -281,9 +281,11 @@ int order_behind_last(l3_ctx* c, hipStream_t stream) {
 }
 // ... and marks the end of this one
 int mark_batch_end(l3_ctx* c, hipStream_t stream) {
-    if (stream != c->stream) HIPCHK(c, hipEventRecord(c->ev_order, stream));   // (calls on the own stream are ordered anyway)
-    c->order_pending = stream != c->stream;
-    c->order_on_own = false;
+    // always recorded: the next batch may come on another stream than this one, whichever of the two is the context's own
+    // (order_behind_last skips the wait only between two batches on the context's own stream: a stream is ordered anyway)
+    HIPCHK(c, hipEventRecord(c->ev_order, stream));
+    c->order_pending = true;
+    c->order_on_own = stream == c->stream;
     return L3_OK;
 }
 
@@ -656,8 +658,9 @@ int l3_encode_submit(l3_ctx* c, const uint8_t* d_text, uint64_t n_bytes, const u
     P.profiled = c->profiling;
     P.light = c->profiling_light;
     HIPCHK(c, launch_encode(c->T, W, A, s, P.profiled ? P.ev : nullptr, false, P.light ? kEvLight : kEvAll));
-    HIPCHK(c, launch_emit_generic(W, A, s));   // nobody reads the status word in between: the (rare) flagged tiles are looked for every time
-    HIPCHK(c, launch_status_out(W, P.h_status, s, 2));   // (a batch that needs a host-driven pass is run again by its wait)
+    // nobody reads the status word in between, so the (rare) tiles the fast scatter flags are looked for every time; the same
+    // launch hands the status word out and clears it (a batch that needs a host-driven pass is run again by its wait)
+    HIPCHK(c, launch_finish(W, A, P.h_status, s));
     if ((rc = mark_batch_end(c, s))) return rc;
     HIPCHK(c, hipEventRecord(P.done, s));
     P.A = A; P.stream = s; P.in_use = true;
@@ -680,7 +683,9 @@ int l3_encode_wait(l3_ctx* c, int ticket, uint64_t* n_tok) {
     if (st.flags & (kRetryFlags | kSeqPending | kGiantPending | kTooLong)) {
         // the batch needs a larger workspace or the host-driven passes (long pre-tokens with invalid UTF-8, giant pieces):
         // once more, synchronously (encode_core waits for the other pending batches first)
-        int rc = encode_core(c, P.A, P.stream, n_tok, nullptr);
+        // (on the context's own stream: the caller's stream handle was only good for the submit -- it may be gone by now --,
+        // and the batch's event has been waited for, so no ordering is lost)
+        int rc = encode_core(c, P.A, c->stream, n_tok, nullptr);
         if (rc == L3_E_OUTPUT_CAP) c->err = "output buffer too small";
         return rc;
     }

@@ -81,9 +81,9 @@ struct Status {
     uint32_t slow_count;        // entries appended so far (may exceed capacity: overflow)
     uint32_t flags;             // kOvf* / kBadOffsets
     uint32_t generic_tiles;     // tiles the fast emit kernel left to the generic one (the host launches it only then)
-    uint32_t pad1;
+    uint32_t done_blocks;       // workgroups of finish_kernel that are through (the last one hands the word to the host)
     unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
-    unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the scan)
+    unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the wave of the emit kernel that has tile 0)
     unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)
     // Per shard (shard = tile % kMissShards), each on a cache line of its own: atomics that return a value and
     // share an address (or a line) queue up behind each other, ~10^4 of them cost tens of microseconds.
@@ -215,6 +215,8 @@ hipError_t launch_giants_rounds(const Tables& T, const Workspace& W, uint64_t n_
 hipError_t launch_giants_store(const Workspace& W, uint64_t n_syms, void* flat, hipStream_t stream);
 // The second half of the final scatter, for the tiles the fast emit kernel flagged (Status::generic_tiles > 0).
 hipError_t launch_emit_generic(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
+// launch_emit_generic + launch_status_out(clear = 2) as ONE launch (the end of a stream-ordered batch).
+hipError_t launch_finish(const Workspace& W, const EncodeArgs& A, Status* host_dst, hipStream_t stream);
 // Decode: ids -> bytes (tokenizer.go:339-354) in blocks of ids, whatever the sequences are: block sums, their scan, then the
 // bytes and the sequence offsets.  block_base: decode_blocks(n_ids) + 1 words of workspace.
 uint64_t decode_blocks(uint64_t n_ids);

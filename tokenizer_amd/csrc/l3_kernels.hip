@@ -17,9 +17,9 @@
 //                  WINDOW items of 1,920 symbols: cut points where no vocabulary entry can span, every piece merged by
 //                  the exact round-based parallel greedy merge, token ids into a sparse per-symbol image; pieces of
 //                  32,768 symbols and more are listed for the grid-wide merge (l3_giant.hip, driven by the host)
-//   block_totals_kernel, scan_kernel   per-tile output bases: totals per 1,024 tiles, their exclusive scan
-//                  (one launch with the last workgroup scanning was tried: no faster, two fences more); the launch of
-//                  the first also carries the finish_window workgroups that compact the window images
+//   block_totals_kernel   per-tile output bases inside blocks of 1,024 tiles and the totals of the blocks (the waves
+//                  of the emit kernels add the block totals in front of their tile up themselves: no scan launch); the
+//                  launch also carries the finish_window workgroups that compact the window images
 //   emit_kernel    scatter to the final token array, per-document offsets, BOS/EOS (tokenizer.go:225-262);
 //   emit_generic_kernel   the tiles the fast one flags
 //   status_out_kernel     the status word to page-locked host memory, cleared for the next batch
@@ -2465,41 +2465,24 @@ __global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, u
     }
     if (threadIdx.x == 0) W.tile_base[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(Workspace W, EncodeArgs A, uint64_t n_blocks) {
-    __shared__ unsigned long long wsum[kScanThreads / 64];
-    __shared__ unsigned long long carry_s;
-    if (W.status->flags & (kBadOffsets | kGiantPending | kSeqPending)) return;
-    const int tid = threadIdx.x;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < n_blocks; base += kScanThreads) {
-        uint64_t t = base + tid;
-        unsigned long long v = t < n_blocks ? W.tile_base[t] : 0ull;
-        unsigned long long inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            unsigned long long o = __shfl_up(inc, d, 64);
-            if (lane_id() >= d) inc += o;
-        }
-        if (lane_id() == 63) wsum[tid >> 6] = inc;
-        __syncthreads();
-        unsigned long long pre = carry_s, tot = 0;
-        for (int i = 0; i < kScanThreads / 64; i++) {
-            if (i < (tid >> 6)) pre += wsum[i];
-            tot += wsum[i];
-        }
-        if (t < n_blocks) W.tile_base[t] = pre + inc - v;
-        __syncthreads();
-        if (tid == 0) carry_s += tot;
-        __syncthreads();
+// Tokens of the blocks of kScanBlock tiles in front of block `blk`, and of all blocks (block_totals_kernel leaves the totals
+// in W.tile_base): every wave that needs them adds them up itself -- 18 values for a 64 MiB batch --, which costs less than
+// the launch of a kernel that scans them.  All 64 lanes must be active; the results are uniform.
+__device__ __forceinline__ void block_prefix(const Workspace& W, uint32_t blk, uint32_t n_blocks, unsigned long long* before,
+                                             unsigned long long* all) {
+    unsigned long long pre = 0, tot = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 64) {   // (uniform)
+        const uint32_t b = b0 + (uint32_t)lane_id();
+        const unsigned long long v = b < n_blocks ? W.tile_base[b] : 0ull;
+        tot += v;
+        if (b < blk) pre += v;
     }
-    if (tid == 0) {
-        unsigned long long total = carry_s;
-        uint32_t be = (A.flags & 1u) + ((A.flags >> 1) & 1u);
-        total += (unsigned long long)A.n_docs * be;
-        W.status->total_tokens = total;
-        if (total > A.out_cap) atomicOr(&W.status->flags, kOvfOut);
-    }
+    pre = wave_iscan64(pre);
+    tot = wave_iscan64(tot);
+    *before = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pre >> 32), 63) << 32) |
+              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pre, 63);
+    *all = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tot >> 32), 63) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tot, 63);
 }
 
 // ---- final scatter -------------------------------------------------------------------------------------
@@ -2557,10 +2540,16 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
     if (tile >= n_tiles) return;   // (whole waves: nothing below synchronises across waves)
     // every parameter load is requested before the first branch: one memory round trip, not three
     const TileRec rec = W.tile_rec[tile];
-    const unsigned long long blk_base = W.tile_base[tile / kScanBlock];
     const uint32_t fl = W.status->flags;
-    const unsigned long long total_tokens = W.status->total_tokens;
+    const uint32_t n_blocks = (n_tiles + (uint32_t)kScanBlock - 1u) / (uint32_t)kScanBlock;
+    unsigned long long blk_base, total_tokens;
+    block_prefix(W, (uint32_t)(tile / kScanBlock), n_blocks, &blk_base, &total_tokens);
     if (fl & (kFatalFlags | kRetryFlags | kGiantPending | kSeqPending)) return;
+    total_tokens += (unsigned long long)A.n_docs * ((A.flags & 1u) + ((A.flags >> 1) & 1u));
+    if (tile == 0 && lane == 0) {   // tokens of the whole batch incl. BOS / EOS: what the caller's buffer must hold
+        W.status->total_tokens = total_tokens;
+        if (total_tokens > A.out_cap) atomicOr(&W.status->flags, kOvfOut);
+    }
     if (total_tokens > A.out_cap) return;
     const uint32_t n_items = rec.n_items;
     const uint64_t d_lo = rec.d_lo, d_hi = rec.d_hi;
@@ -2678,7 +2667,9 @@ __device__ void emit_tile_generic(const Workspace& W, const EncodeArgs& A, uint6
     for (int i = tid; i <= (int)n_items; i += kTileThreads) docinc[i] = 0;
     if (tid == 0) q_n = 0;
     // tokens before this tile: scanned block base + the tiles of the block that precede it
-    const unsigned long long base = W.tile_base[tile / kScanBlock] + W.tile_rec[tile].pre;
+    unsigned long long blk_base, all_blocks;
+    block_prefix(W, (uint32_t)(tile / kScanBlock), (uint32_t)((n_tiles + kScanBlock - 1) / kScanBlock), &blk_base, &all_blocks);
+    const unsigned long long base = blk_base + W.tile_rec[tile].pre;
     __syncthreads();   // (the counters are cleared by other threads than those that count: without this barrier a document
                        // start was lost once in some ten thousand heavy tiles, and the tile's tokens landed one slot early)
     for (uint64_t d = d_lo + tid; d < d_hi; d += kTileThreads) atomicAdd(&docinc[W.doc_item[d]], 1u);
@@ -2744,7 +2735,7 @@ __global__ __launch_bounds__(kTileThreads) void emit_generic_kernel(Workspace W,
     __shared__ uint32_t q_n;
     const uint32_t fl = W.status->flags;
     if (fl & (kFatalFlags | kRetryFlags | kGiantPending | kSeqPending)) return;
-    if (W.status->total_tokens > A.out_cap) return;
+    if (fl & kOvfOut) return;   // (set by the fast kernel, which ran before)
     const uint64_t t0 = (uint64_t)blockIdx.x * kGenericPer;
     for (uint64_t t = t0; t < t0 + kGenericPer && t < n_tiles; t++) {
         if (!W.tile_flag[t]) continue;   // uniform over the workgroup
@@ -2943,8 +2934,6 @@ static hipError_t launch_totals_scan(const Workspace& W, const EncodeArgs& A, hi
     hipLaunchKernelGGL(block_totals_kernel, dim3((uint32_t)n_blocks + L3_FINISH_GRID), dim3(kScanBlock), 0, stream, W, n_tiles, A.n_docs,
                        (uint32_t)n_blocks);
     L3_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, W, A, n_blocks);
-    L3_LAUNCH_CHECK();
     return hipSuccess;
 }
 
@@ -2962,6 +2951,55 @@ __global__ __launch_bounds__(256) void status_out_kernel(Status* st, Status* hos
     __syncthreads();
     if (clear == 0 || (clear == 1 && (fl & (kSeqPending | kGiantPending)))) return;
     for (uint32_t i = threadIdx.x; i < n_words; i += 256) src[i] = 0;
+}
+// The two launches that end a stream-ordered batch in one: the tiles the fast emit kernel flagged (looked for by a fixed,
+// small grid: normally there are none), then the status word to the host and back to zero by whichever workgroup is
+// through last -- every other workgroup has made its last access to the word by then.
+constexpr int kFinishBlocks = 256;
+__global__ __launch_bounds__(kTileThreads) void finish_kernel(Workspace W, EncodeArgs A, uint64_t n_tiles, Status* host_dst) {
+    __shared__ uint32_t docinc[kTileCap + 1];
+    __shared__ uint32_t tokpre[kTileCap + 1];
+    __shared__ unsigned long long tmp64[8];
+    __shared__ unsigned long long q_out[kEmitQueue];
+    __shared__ int32_t q_item[kEmitQueue];
+    __shared__ uint32_t q_n, n_flagged, s_last;
+    __shared__ uint32_t flagged[kTileThreads];
+    const uint32_t fl = W.status->flags;
+    if (!(fl & (kFatalFlags | kRetryFlags | kGiantPending | kSeqPending | kOvfOut))) {
+        for (uint64_t t0 = (uint64_t)blockIdx.x * kTileThreads; t0 < n_tiles; t0 += (uint64_t)gridDim.x * kTileThreads) {   // (uniform)
+            if (threadIdx.x == 0) n_flagged = 0;
+            __syncthreads();
+            const uint64_t t = t0 + threadIdx.x;
+            if (t < n_tiles && W.tile_flag[t]) flagged[atomicAdd(&n_flagged, 1u)] = (uint32_t)t;
+            __syncthreads();
+            const uint32_t nf = n_flagged;
+            for (uint32_t k = 0; k < nf; k++) {
+                emit_tile_generic(W, A, flagged[k], n_tiles, docinc, tokpre, tmp64, q_out, q_item, &q_n);
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&W.status->done_blocks, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    uint32_t* src = reinterpret_cast<uint32_t*>(W.status);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(host_dst);
+    constexpr uint32_t n_words = sizeof(Status) / 4;
+    for (uint32_t i = threadIdx.x; i < n_words; i += kTileThreads) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_words; i += kTileThreads) src[i] = 0;
+}
+hipError_t launch_finish(const Workspace& W, const EncodeArgs& A, Status* host_dst, hipStream_t stream) {
+    const uint64_t n_tiles = num_tiles(A.n_bytes);
+    uint64_t grid = (n_tiles + kTileThreads - 1) / kTileThreads;
+    if (grid > kFinishBlocks) grid = kFinishBlocks;
+    hipLaunchKernelGGL(finish_kernel, dim3((uint32_t)grid), dim3(kTileThreads), 0, stream, W, A, n_tiles, host_dst);
+    L3_LAUNCH_CHECK();
+    return hipSuccess;
 }
 hipError_t launch_status_out(const Workspace& W, Status* host_dst, hipStream_t stream, int clear) {
     hipLaunchKernelGGL(status_out_kernel, dim3(1), dim3(256), 0, stream, W.status, host_dst, clear);
