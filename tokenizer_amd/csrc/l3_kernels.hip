@@ -226,7 +226,7 @@ struct TileLds {
 };
 constexpr int kListPer = 16;
 static_assert(kListPer * kTileThreads >= kTile && 64 % kListPer == 0 && kBack % kListPer == 0, "list compaction geometry");
-enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NSLOW, TV_SLOW0, TV_NAB, TV_ANYINV, TV_NDEF, TV_OWNINV, TV_ANYSPS, TV_COUNT = 12 };
+enum { TV_NPRE = 0, TV_NEED, TV_MB, TV_NSLOW, TV_SLOW0, TV_NAB, TV_ANYINV, TV_NDEF, TV_OWNINV, TV_ANYSPS, TV_RARE, TV_COUNT = 12 };
 
 struct TileSrc {  // byte source over the tile's LDS image, LOCAL coordinates [0, n)
     const TileLds* R;
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     for (int i = tid; i < kWords + 2; i += kTileThreads) {
         R.bm[B_DS][i] = 0; R.bm[B_SPS][i] = 0; R.bm[B_SPB][i] = 0; R.bm[B_SPE][i] = 0; R.bm[B_CE2][i] = 0; R.bm[B_CE3][i] = 0;
     }
-    if (tid == 0) { vars[TV_NSLOW] = 0; vars[TV_NAB] = 0; vars[TV_NDEF] = 0; vars[TV_ANYINV] = 0; vars[TV_ANYSPS] = 0; }
+    if (tid == 0) { vars[TV_NSLOW] = 0; vars[TV_NAB] = 0; vars[TV_NDEF] = 0; vars[TV_ANYINV] = 0; vars[TV_ANYSPS] = 0; vars[TV_RARE] = 0; }
     if (tid <= kVocabInline) {   // mask of the first `tid` bytes of three words + the length tag of a vocabulary slot
         const uint32_t l = (uint32_t)tid;
         mk[tid] = make_uint4(l >= 4u ? 0xFFFFFFFFu : (1u << (8u * l)) - 1u, l >= 8u ? 0xFFFFFFFFu : (l > 4u ? (1u << (8u * (l - 4u))) - 1u : 0u),
@@ -693,30 +693,15 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             atomicOr(&R.bm[B_DS][(pos - g_lo) >> 6], 1ull << ((pos - g_lo) & 63));
         }
     }
-    __syncthreads();
-    L3_PH(1);
-
-    // -- bytes outside ASCII (generic UTF-8 decode + class table), contraction letters after an apostrophe,
-    //    special-token literals after '<' (state_machine.go:36,131-148,310-320; special.go:12)
-    const TileSrc src{&R, n, hard};
+    // -- contraction letters after an apostrophe (state_machine.go:131-148); the masks of the ASCII bytes.  A thread that
+    //    holds bytes outside ASCII or a '<' says so: those take a phase of their own below, which pure ASCII text without
+    //    '<' skips together with its barrier
+    const uint32_t lt_mask = (A.flags & kNoSpecial) ? 0u : m_lt;
+    uint32_t hi_mask = 0;
     if (cls_thread) {
         const uint32_t valid = c0 + 16 <= n ? 0xFFFFu : (c0 < n ? (1u << (n - c0)) - 1u : 0u);
-        uint32_t m_inv = 0, m_nx = 0;
-        uint32_t hi = ~m_rs & valid;  // bytes >= 0x80
-        while (hi) {
-            const int k = __builtin_ctz(hi);
-            hi &= hi - 1;
-            const uint32_t wd = byte_info(src, c0 + k, T.cls_stage1, T.cls_blocks);
-            if (wd & I_RUNE) {
-                const uint32_t c = wd & I_CLS, bit = 1u << k;
-                m_rs |= bit;
-                if (c == C_L) m_l |= bit;
-                else if (c == C_N) { m_n |= bit; m_nx |= bit; }
-                else if (c == C_WS) m_ws |= bit;
-                if (wd & I_INVALID) m_inv |= bit;
-            }
-        }
-        if (m_inv) vars[TV_ANYINV] = 1;   // (every writer stores the same value)
+        hi_mask = ~m_rs & valid;  // bytes >= 0x80
+        if (hi_mask | lt_mask) vars[TV_RARE] = 1;   // (every writer stores the same value)
         uint32_t ap = m_apos;
         while (ap) {
             const int q = c0 + __builtin_ctz(ap);
@@ -726,7 +711,50 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             if ((b1 == 'r' && b2 == 'e') || (b1 == 'v' && b2 == 'e') || (b1 == 'l' && b2 == 'l'))
                 atomicOr(&R.bm[B_CE3][(q + 3) >> 6], 1ull << ((q + 3) & 63));
         }
-        uint32_t lt = (A.flags & kNoSpecial) ? 0u : m_lt;
+        uint16_t* h;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_RS]); h[tid] = (uint16_t)m_rs;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_L]); h[tid] = (uint16_t)m_l;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_N]); h[tid] = (uint16_t)m_n;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_NL]); h[tid] = (uint16_t)m_nl;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_SP]); h[tid] = (uint16_t)m_sp;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_WS]); h[tid] = (uint16_t)m_ws;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_APOS]); h[tid] = (uint16_t)m_apos;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_INV]); h[tid] = 0;
+        h = reinterpret_cast<uint16_t*>(R.bm[B_NX]); h[tid] = 0;
+    }
+    __syncthreads();
+    L3_PH(1);
+
+    // -- bytes outside ASCII (generic UTF-8 decode + class table), special-token literals after '<'
+    //    (state_machine.go:36,310-320; special.go:12): only in tiles that hold any (uniform)
+    const TileSrc src{&R, n, hard};
+    if (vars[TV_RARE]) {
+        if (hi_mask) {
+            uint32_t m_inv = 0, m_nx = 0;
+            uint32_t hi = hi_mask;
+            while (hi) {
+                const int k = __builtin_ctz(hi);
+                hi &= hi - 1;
+                const uint32_t wd = byte_info(src, c0 + k, T.cls_stage1, T.cls_blocks);
+                if (wd & I_RUNE) {
+                    const uint32_t c = wd & I_CLS, bit = 1u << k;
+                    m_rs |= bit;
+                    if (c == C_L) m_l |= bit;
+                    else if (c == C_N) { m_n |= bit; m_nx |= bit; }
+                    else if (c == C_WS) m_ws |= bit;
+                    if (wd & I_INVALID) m_inv |= bit;
+                }
+            }
+            if (m_inv) vars[TV_ANYINV] = 1;   // (every writer stores the same value)
+            uint16_t* h;   // (a thread's half-words are its own)
+            h = reinterpret_cast<uint16_t*>(R.bm[B_RS]); h[tid] = (uint16_t)m_rs;
+            h = reinterpret_cast<uint16_t*>(R.bm[B_L]); h[tid] = (uint16_t)m_l;
+            h = reinterpret_cast<uint16_t*>(R.bm[B_N]); h[tid] = (uint16_t)m_n;
+            h = reinterpret_cast<uint16_t*>(R.bm[B_WS]); h[tid] = (uint16_t)m_ws;
+            h = reinterpret_cast<uint16_t*>(R.bm[B_INV]); h[tid] = (uint16_t)m_inv;
+            h = reinterpret_cast<uint16_t*>(R.bm[B_NX]); h[tid] = (uint16_t)m_nx;
+        }
+        uint32_t lt = lt_mask;
         while (lt) {
             const int q = c0 + __builtin_ctz(lt);
             lt &= lt - 1;
@@ -742,18 +770,8 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
                 }
             }
         }
-        uint16_t* h;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_RS]); h[tid] = (uint16_t)m_rs;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_L]); h[tid] = (uint16_t)m_l;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_N]); h[tid] = (uint16_t)m_n;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_NL]); h[tid] = (uint16_t)m_nl;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_SP]); h[tid] = (uint16_t)m_sp;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_WS]); h[tid] = (uint16_t)m_ws;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_APOS]); h[tid] = (uint16_t)m_apos;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_INV]); h[tid] = (uint16_t)m_inv;
-        h = reinterpret_cast<uint16_t*>(R.bm[B_NX]); h[tid] = (uint16_t)m_nx;
+        __syncthreads();
     }
-    __syncthreads();
     L3_PH(2);
 
     // -- start-of-pre-token bits (one wave), digit runs that need more context than the halo holds
@@ -909,10 +927,9 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
             for (int u = 0; u < kLookU; u++) {
                 const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
                 const uint32_t diff = (sl[u].w[0] ^ a0[u]) | (sl[u].w[1] ^ a1[u]) | (sl[u].w[2] ^ a2[u]) | ((sl[u].w[3] ^ tag[u]) & ~0x1FFFFu);
-                if ((m_fast >> u) & 1u) {
-                    if (diff == 0) out0[k] = (int32_t)(sl[u].w[3] & 0x1FFFFu);
-                    else m_a |= 1u << u;
-                }
+                const bool probed = (m_fast >> u) & 1u, hit = probed && diff == 0;
+                if (hit) out0[k] = (int32_t)(sl[u].w[3] & 0x1FFFFu);
+                m_a |= (probed && !hit) ? 1u << u : 0u;
             }
             // one scan per wave for both lists (the two counts packed in one word), one LDS atomic per wave
             const uint32_t cnt_a = (uint32_t)__popc(m_a), cnt_b = (uint32_t)__popc(m_b);
@@ -927,8 +944,12 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
 #pragma unroll
                 for (int u = 0; u < kLookU; u++) {
                     const uint32_t k = base + (uint32_t)u * kTileThreads + tid;
-                    if ((m_a >> u) & 1u) { if (pa < (uint32_t)kLstCap) lst[pa] = (uint16_t)k; pa++; }
-                    if ((m_b >> u) & 1u) { if (pb < (uint32_t)kLstCap) lst[kLstCap - 1 - pb] = (uint16_t)k; pb++; }
+                    // (an index beyond the list is clamped: the lists have overflowed then and are not looked at)
+                    const uint32_t to_a = (m_a >> u) & 1u, to_b = (m_b >> u) & 1u;
+                    if (to_a) lst[pa < (uint32_t)kLstCap ? pa : (uint32_t)kLstCap - 1u] = (uint16_t)k;
+                    if (to_b) lst[(uint32_t)kLstCap - 1u - (pb < (uint32_t)kLstCap ? pb : (uint32_t)kLstCap - 1u)] = (uint16_t)k;
+                    pa += to_a;
+                    pb += to_b;
                 }
             }
         }
