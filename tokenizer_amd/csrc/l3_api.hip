@@ -210,6 +210,7 @@ size_t carve_workspace(uint8_t* base, uint64_t n_bytes, uint64_t n_docs, const C
     W.allow_giants = 1;
     W.giants = reinterpret_cast<Giant*>(take(kMaxGiants * sizeof(Giant)));
     W.gstate = reinterpret_cast<GiantState*>(take(sizeof(GiantState)));
+    W.runs = reinterpret_cast<BigRun*>(take((kMaxBigRuns + kMaxHugeRuns) * sizeof(BigRun)));
     W.win = reinterpret_cast<WinItem*>(take(K.win_cap * sizeof(WinItem)));
     W.win_live = reinterpret_cast<uint32_t*>(take(K.win_cap * 4));
     W.win_first = reinterpret_cast<uint32_t*>(take(K.win_cap * 4));
@@ -400,6 +401,11 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         if (c->h_status->generic_tiles && !(c->h_status->flags & (kFatalFlags | kRetryFlags | kOvfOut))) {
             // tiles with empty documents or token floods: the generic scatter, launched only when the fast one asks
             HIPCHK(c, launch_emit_generic(W, A, stream));
+            HIPCHK(c, hipStreamSynchronize(stream));
+        }
+        if ((c->h_status->big_runs | c->h_status->huge_runs) && !(c->h_status->flags & (kFatalFlags | kRetryFlags | kOvfOut))) {
+            // pre-tokens of thousands of tokens: copied to the output by the whole grid
+            HIPCHK(c, launch_copy_runs(W, A, (long long)c->h_status->big_runs, (long long)c->h_status->huge_runs, stream));
             HIPCHK(c, hipStreamSynchronize(stream));
         }
         if ((rc = mark_batch_end(c, stream))) return rc;
@@ -775,6 +781,10 @@ int l3_encode_batch_device_noalloc(l3_ctx* c, const uint8_t* d_text, uint64_t n_
     if (st.flags & kOvfOut) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
     if (st.generic_tiles) {
         HIPCHK(c, launch_emit_generic(W, A, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    if (st.big_runs | st.huge_runs) {
+        HIPCHK(c, launch_copy_runs(W, A, (long long)st.big_runs, (long long)st.huge_runs, s));
         HIPCHK(c, hipStreamSynchronize(s));
     }
     return L3_OK;

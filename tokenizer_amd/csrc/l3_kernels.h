@@ -85,6 +85,8 @@ struct Status {
     unsigned long long pool_used;        // tokens reserved in the slow pool (may exceed capacity)
     unsigned long long total_tokens;     // tokens of the whole batch incl. BOS/EOS (written by the wave of the emit kernel that has tile 0)
     unsigned long long scratch_used;     // bytes reserved in the giant-pre-token scratch (may exceed capacity)
+    uint32_t big_runs, huge_runs;        // runs of tokens the emit kernel left to copy_runs, by size class (may exceed kMaxBigRuns /
+                                         // kMaxHugeRuns: the surplus was copied by the wave that met it)
     // Per shard (shard = tile % kMissShards), each on a cache line of its own: atomics that return a value and
     // share an address (or a line) queue up behind each other, ~10^4 of them cost tens of microseconds.
     struct alignas(128) Shard {
@@ -124,6 +126,13 @@ struct GiantState {
     uint32_t wave_live[kGiantWaves];
     GiantSeg wave_seg[kGiantWaves];
 };
+// A pre-token of thousands of tokens (a long run of ideographs, a megabyte of one letter) is ONE item of ONE tile: its tokens
+// are not copied to the output by the wave that emits that tile but listed, and copied by the whole grid (copy_runs).
+constexpr uint32_t kBigRun = 4096;       // tokens from which a run is listed
+constexpr uint32_t kMaxBigRuns = 16384;
+constexpr uint32_t kHugeRun = 65536;     // tokens from which a run is copied in pieces by all workgroups (else: one workgroup)
+constexpr uint32_t kMaxHugeRuns = 1024;
+struct BigRun { uint64_t src, dst, n; };  // pool offset, output index, tokens
 constexpr int kMissShards = 64;
 // a short deferred pre-token (input of merge_kernel).  Its result is one word of miss_res: bits 0..7 = n tokens;
 // n <= 3: the tokens themselves in bits 8.., 17 bits each; n > 3: bits 8.. = offset of the tokens in the pool
@@ -168,6 +177,7 @@ struct Workspace {
     uint32_t allow_giants;  // 0: no piece is left to the grid-wide merge (the allocation-free entry point: that path allocates)
     Giant* giants;          // [kMaxGiants]
     GiantState* gstate;
+    BigRun* runs;           // [kMaxBigRuns + kMaxHugeRuns]: the big runs, behind them the huge ones
     WinItem* win;           // [win_cap] window items of the long pre-tokens
     uint32_t* win_live;     // [win_cap] tokens in the image slots of each window's range
     uint32_t* win_first;    // [win_cap] symbol position of the first cut inside each window, 0xFFFFFFFF: none
@@ -217,6 +227,9 @@ hipError_t launch_giants_store(const Workspace& W, uint64_t n_syms, void* flat, 
 hipError_t launch_emit_generic(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
 // launch_emit_generic + launch_status_out(clear = 2) as ONE launch (the end of a stream-ordered batch).
 hipError_t launch_finish(const Workspace& W, const EncodeArgs& A, Status* host_dst, hipStream_t stream);
+// Copies the runs of tokens the emit kernel listed (Status::big_runs, huge_runs) to the output.  n_big, n_huge: their numbers as
+// the host read them from the status word, or -1: the kernel reads them from the status word on the device.
+hipError_t launch_copy_runs(const Workspace& W, const EncodeArgs& A, long long n_big, long long n_huge, hipStream_t stream);
 // Decode: ids -> bytes (tokenizer.go:339-354) in blocks of ids, whatever the sequences are: block sums, their scan, then the
 // bytes and the sequence offsets.  block_base: decode_blocks(n_ids) + 1 words of workspace.
 uint64_t decode_blocks(uint64_t n_ids);

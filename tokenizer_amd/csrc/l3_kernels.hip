@@ -2662,6 +2662,16 @@ __global__ __launch_bounds__(kTileThreads, L3_EMIT_OCC) void emit_kernel(Workspa
                 const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)rel, b);
                 const uint64_t po = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(loc[s] >> 32), b) << 32) |
                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)loc[s], b);
+                if (cn > kBigRun) {   // listed for copy_runs: other workgroups copy it
+                    const bool huge = cn > kHugeRun;
+                    uint32_t idx = 0;
+                    if (lane == 0) idx = atomicAdd(huge ? &W.status->huge_runs : &W.status->big_runs, 1u);
+                    idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+                    if (idx < (huge ? kMaxHugeRuns : kMaxBigRuns)) {
+                        if (lane == 0) W.runs[(huge ? kMaxBigRuns : 0u) + idx] = BigRun{po, (uint64_t)(o_base + (long long)rl), cn};
+                        continue;
+                    }
+                }
                 const int32_t* src = W.pool + po;
                 int32_t* dst = out + (o_base + (long long)rl);
                 for (uint32_t k = lane; k < cn; k += 64) dst[k] = src[k];
@@ -2973,6 +2983,38 @@ __global__ __launch_bounds__(256) void status_out_kernel(Status* st, Status* hos
     if (clear == 0 || (clear == 1 && (fl & (kSeqPending | kGiantPending)))) return;
     for (uint32_t i = threadIdx.x; i < n_words; i += 256) src[i] = 0;
 }
+// The listed runs of tokens (BigRun) from the pool to the output: a big run by one workgroup (the runs dealt out over the
+// grid in turn), a huge one in pieces of kRunChunk tokens by all workgroups.
+constexpr uint32_t kRunChunk = 8192;
+__device__ void copy_runs(const Workspace& W, const EncodeArgs& A, uint32_t n_big, uint32_t n_huge, uint32_t block, uint32_t n_blocks) {
+    for (uint32_t e = block; e < n_big; e += n_blocks) {   // (uniform)
+        const BigRun r = W.runs[e];
+        for (uint64_t k = threadIdx.x; k < r.n; k += blockDim.x) A.out_tok[r.dst + k] = W.pool[r.src + k];
+    }
+    uint64_t g = 0;   // pieces of the huge runs before the current one
+    for (uint32_t e = 0; e < n_huge; e++) {   // (uniform)
+        const BigRun r = W.runs[kMaxBigRuns + e];
+        const uint64_t pieces = (r.n + kRunChunk - 1) / kRunChunk;
+        for (uint64_t c = ((uint64_t)block + n_blocks - g % n_blocks) % n_blocks; c < pieces; c += n_blocks) {
+            const uint64_t lo = c * kRunChunk, hi = lo + kRunChunk < r.n ? lo + kRunChunk : r.n;
+            for (uint64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) A.out_tok[r.dst + k] = W.pool[r.src + k];
+        }
+        g += pieces;
+    }
+}
+__global__ __launch_bounds__(kTileThreads) void copy_runs_kernel(Workspace W, EncodeArgs A, long long n_big_host, long long n_huge_host) {
+    const uint32_t fl = W.status->flags;
+    if (n_big_host < 0 && (fl & (kFatalFlags | kRetryFlags | kGiantPending | kSeqPending | kOvfOut))) return;
+    const uint32_t nb = n_big_host < 0 ? W.status->big_runs : (uint32_t)n_big_host;
+    const uint32_t nh = n_huge_host < 0 ? W.status->huge_runs : (uint32_t)n_huge_host;
+    copy_runs(W, A, nb < kMaxBigRuns ? nb : kMaxBigRuns, nh < kMaxHugeRuns ? nh : kMaxHugeRuns, blockIdx.x, gridDim.x);
+}
+hipError_t launch_copy_runs(const Workspace& W, const EncodeArgs& A, long long n_big, long long n_huge, hipStream_t stream) {
+    hipLaunchKernelGGL(copy_runs_kernel, dim3(1024), dim3(kTileThreads), 0, stream, W, A, n_big, n_huge);
+    L3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 // The two launches that end a stream-ordered batch in one: the tiles the fast emit kernel flagged (looked for by a fixed,
 // small grid: normally there are none), then the status word to the host and back to zero by whichever workgroup is
 // through last -- every other workgroup has made its last access to the word by then.
@@ -2999,6 +3041,8 @@ __global__ __launch_bounds__(kTileThreads) void finish_kernel(Workspace W, Encod
                 __syncthreads();
             }
         }
+        const uint32_t nb = W.status->big_runs, nh = W.status->huge_runs;
+        copy_runs(W, A, nb < kMaxBigRuns ? nb : kMaxBigRuns, nh < kMaxHugeRuns ? nh : kMaxHugeRuns, blockIdx.x, gridDim.x);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -3092,6 +3136,8 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
     L3_LAUNCH_CHECK();
     if (emit_only) {   // the re-run after the caller enlarged its buffer: the flags of the first run are gone
         hipError_t e_ = launch_emit_generic(W, A, stream);
+        if (e_ != hipSuccess) return e_;
+        e_ = launch_copy_runs(W, A, -1, -1, stream);
         if (e_ != hipSuccess) return e_;
     }
     L3_EV(kEvEmit);
