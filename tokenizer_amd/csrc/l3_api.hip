@@ -214,6 +214,7 @@ size_t carve_workspace(uint8_t* base, uint64_t n_bytes, uint64_t n_docs, const C
     W.win = reinterpret_cast<WinItem*>(take(K.win_cap * sizeof(WinItem)));
     W.win_live = reinterpret_cast<uint32_t*>(take(K.win_cap * 4));
     W.win_first = reinterpret_cast<uint32_t*>(take(K.win_cap * 4));
+    W.win_cnt = reinterpret_cast<uint32_t*>(take(K.win_cap * 4));
     W.win_cap = K.win_cap;
     W.status = status;
     W.slow_cap = K.slow_cap;
@@ -451,7 +452,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         c->counters[3] = st.scratch_used;
         c->counters[5] = miss_total;
         c->counters[6] = st.slow_q.count;
-        c->slow_grid = st.slow_count > 64 ? 0u : 32u;   // (the slow list feeds the wave pass and slow_kernel)
+        c->slow_grid = (st.slow_count > 64 || st.slow_q.count > 32) ? 0u : 32u;   // (the slow list feeds the wave pass and slow_kernel)
         *n_tok = st.total_tokens;
         if (W_out) *W_out = W;
         return (st.flags & kOvfOut) ? L3_E_OUTPUT_CAP : L3_OK;
@@ -706,7 +707,7 @@ int l3_encode_wait(l3_ctx* c, int ticket, uint64_t* n_tok) {
     for (int i = 0; i < kMissShards; i++) { miss_total += st.shard[i].miss_count; mpool_total += st.shard[i].pool_used; }
     c->counters[0] = num_tiles(P.A.n_bytes); c->counters[1] = st.slow_count; c->counters[2] = st.pool_used + mpool_total;
     c->counters[3] = st.scratch_used; c->counters[4] = 0; c->counters[5] = miss_total; c->counters[6] = st.slow_q.count; c->counters[7] = 0;
-    c->slow_grid = st.slow_count > 64 ? 0u : 32u;   // (the slow list feeds the wave pass and slow_kernel)
+    c->slow_grid = (st.slow_count > 64 || st.slow_q.count > 32) ? 0u : 32u;   // (the slow list feeds the wave pass and slow_kernel)
     *n_tok = st.total_tokens;
     if (st.flags & kOvfOut) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
     return L3_OK;

@@ -54,10 +54,11 @@ struct SlowEntry {
     uint32_t count;      // in (tile kernel): 1 = its bytes are known to be valid UTF-8; out: tokens produced
     uint32_t pad;
     uint64_t pool_off;   // first token in the slow pool
+    uint64_t xoff;       // a long pre-token with invalid UTF-8: offset of its symbol array in the scratch
 };
 constexpr uint64_t kEntrySequential = 1ull << 63;
-constexpr uint64_t kEntryExpanded = 1ull << 62;   // ... and its symbols are written out: `start` = their offset in the scratch, the
-                                                  // second pass of slow_kernel takes its windows one item each
+constexpr uint64_t kEntryExpanded = 1ull << 62;   // ... and its symbols are written out (SlowEntry::xoff): the second pass of slow_kernel
+                                                  // takes its windows one item each
 constexpr uint64_t kEntryWinMask = ~(kEntrySequential | kEntryExpanded);
 // A long pre-token is worked on in windows of kWin symbols, one work item each (slow_kernel).
 struct WinItem { uint32_t entry, k; };
@@ -98,7 +99,7 @@ struct Status {
     // launch take it a few entries at a time, do the entries of known, moderate length themselves and prepare the others
     // (end, room in the pool, window items).  slow_q: over the window items (count of them); slow_kernel's workgroups
     // take those one at a time.
-    struct alignas(128) Queue { uint32_t next, count; } slow_q, mid_q, seq_q;
+    struct alignas(128) Queue { uint32_t next, count; } slow_q, mid_q, seq_q, exp_q;
     // pieces left to the grid-wide merge: their number (may exceed kMaxGiants: the surplus was merged by one workgroup each)
     struct alignas(128) GiantCount { uint32_t count, pad; } giant;
 };
@@ -180,6 +181,7 @@ struct Workspace {
     BigRun* runs;           // [kMaxBigRuns + kMaxHugeRuns]: the big runs, behind them the huge ones
     WinItem* win;           // [win_cap] window items of the long pre-tokens
     uint32_t* win_live;     // [win_cap] tokens in the image slots of each window's range
+    uint32_t* win_cnt;      // [win_cap] symbols of the chunk of bytes each window item of a pre-token with invalid UTF-8 expands
     uint32_t* win_first;    // [win_cap] symbol position of the first cut inside each window, 0xFFFFFFFF: none
     Status* status;
     uint64_t slow_cap, miss_shard_cap, mpool_shard_cap, pool_cap, scratch_cap, win_cap;

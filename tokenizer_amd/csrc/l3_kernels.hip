@@ -97,6 +97,18 @@ __device__ __forceinline__ unsigned long long block_min64(unsigned long long v, 
     __syncthreads();
     return r;
 }
+// sum over the workgroup; tmp: >= NW words of LDS.  Two barriers.
+template <int NW = kTileThreads / 64>
+__device__ __forceinline__ unsigned long long block_sum64(unsigned long long v, unsigned long long* tmp) {
+    v = wave_iscan64(v);
+    __syncthreads();
+    if (lane_id() == 63) tmp[wave_id()] = v;
+    __syncthreads();
+    unsigned long long r = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) r += tmp[i];
+    return r;
+}
 // segmented counter: `cnt` = length of the run at the end of the span, `open` = the span holds no break
 struct Seg { uint32_t cnt, open; };
 __device__ __forceinline__ Seg seg_comb(Seg a, Seg b) {
@@ -495,7 +507,7 @@ __device__ __forceinline__ int32_t tile_deferred_record(const Workspace& W, cons
             se.len = ev == kOpenEnd ? 0u : ev - s;
             se.tile = (uint32_t)tile;
             se.count = valid;   // in: 1 = known to be valid UTF-8
-            se.pad = 0; se.pool_off = 0;
+            se.pad = 0; se.pool_off = 0; se.xoff = 0;
             W.slow[ei] = se;
         }
         ei += kSlowBase;
@@ -2261,6 +2273,64 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
     return a + b + long_cnt;
 }
 
+// Symbols of the bytes [lo, hi) of the pre-token [start, start + len) of the text: one per byte, EF BF BD for a byte that is
+// not valid UTF-8 (state_machine.go:36).  Whole workgroup; every wave takes one contiguous range of the bytes, 64 at a time
+// (order by ballots).  expand_count: the number of symbols, and in *wave_off the symbols in front of the calling wave's range;
+// expand_write: the symbols themselves to xs[0 ..] (wave_off as expand_count gave it).  tmp: 4 words of LDS.
+__device__ __forceinline__ void expand_range(uint32_t lo, uint32_t hi, uint32_t* b0, uint32_t* b1) {
+    const uint32_t n = hi - lo, bw = ((n + kSlowThreads - 1) / kSlowThreads) * 64u, wave = (uint32_t)wave_id();
+    *b0 = lo + (wave * bw < n ? wave * bw : n);
+    *b1 = *b0 + bw < hi ? *b0 + bw : hi;
+}
+__device__ uint32_t expand_count(const Tables& T, const EncodeArgs& A, uint64_t start, uint32_t len, uint32_t lo, uint32_t hi,
+                                 uint32_t* tmp, uint32_t* wave_off) {
+    GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
+    const uint32_t lane = (uint32_t)lane_id(), wave = (uint32_t)wave_id();
+    uint32_t b0, b1;
+    expand_range(lo, hi, &b0, &b1);
+    uint32_t nsym = 0;
+    for (uint32_t base = b0; base < b1; base += 64) {
+        const uint32_t q = base + lane;
+        const bool in = q < b1;
+        const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
+        nsym += (uint32_t)__popcll(__ballot(in)) + 2u * (uint32_t)__popcll(__ballot(inv));
+    }
+    __syncthreads();
+    if (lane == 0) tmp[wave] = nsym;
+    __syncthreads();
+    uint32_t L = 0, so = 0;
+    for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
+        const uint32_t x = tmp[w2];
+        if (w2 < wave) so += x;
+        L += x;
+    }
+    *wave_off = so;
+    return L;
+}
+__device__ void expand_write(const Tables& T, const EncodeArgs& A, uint64_t start, uint32_t len, uint32_t lo, uint32_t hi, uint8_t* xs,
+                             uint32_t wave_off) {
+    GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
+    const uint32_t lane = (uint32_t)lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t b0, b1;
+    expand_range(lo, hi, &b0, &b1);
+    uint32_t o = wave_off;
+    for (uint32_t base = b0; base < b1; base += 64) {
+        const uint32_t q = base + lane;
+        const bool in = q < b1;
+        const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
+        const unsigned long long mi = __ballot(in), mv = __ballot(inv);
+        const uint32_t pos = o + (uint32_t)__popcll(mi & lt) + 2u * (uint32_t)__popcll(mv & lt);
+        if (inv) {
+            xs[pos] = 0xEF; xs[pos + 1] = 0xBF; xs[pos + 2] = 0xBD;
+        } else if (in) {
+            xs[pos] = A.text[start + q];
+        }
+        o += (uint32_t)__popcll(mi) + 2u * (uint32_t)__popcll(mv);
+    }
+}
+constexpr uint32_t kSeqChunk = (uint32_t)kWin / 3u;   // bytes of a pre-token with invalid UTF-8 that one of its window items expands
+
 #ifndef L3_SLOW_OCC
 #define L3_SLOW_OCC 1
 #endif
@@ -2287,7 +2357,7 @@ __global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables 
 #pragma unroll 1
     for (;;) {
         __syncthreads();
-        if (tid == 0) ivars[1] = first ? (int)blockIdx.x : (int)(gridDim.x + atomicAdd(pass ? &W.status->seq_q.next : &W.status->slow_q.next, 1u));
+        if (tid == 0) ivars[1] = first ? (int)blockIdx.x : (int)(gridDim.x + atomicAdd(pass == 2 ? &W.status->exp_q.next : pass ? &W.status->seq_q.next : &W.status->slow_q.next, 1u));
         first = false;
         __syncthreads();
         if ((uint32_t)ivars[1] >= n_items) break;
@@ -2302,11 +2372,37 @@ __global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables 
         const uint64_t slots = sequential ? 3ull * len : (uint64_t)len;
         int32_t* const img = W.pool + W.slow[ei].pool_off + slots;   // the image lies behind the room for the final tokens
         uint32_t total = 0;
-        if (pass) {   // second pass: the windows of the pre-tokens the first pass expanded, one item each
+        // A long pre-token with invalid UTF-8 (its symbols are not its bytes) is expanded to a symbol array in the scratch by all
+        // its window items, each a chunk of kSeqChunk bytes: counted in the first pass, written in the expansion pass (the
+        // host starts it when the status word says kSeqPending), and merged window by window in the second pass.
+        const bool spread = sequential && W.allow_giants && (slots + (uint64_t)kWin - 1) / (uint64_t)kWin > (uint64_t)kSeqInline;
+        if (pass == 2) {   // expansion pass
+            if (!spread) continue;
+            uint32_t* const cnt = W.win_cnt + (win0 & kEntryWinMask);
+            const uint32_t n_win = (uint32_t)((slots + (uint64_t)kWin - 1) / (uint64_t)kWin);
+            unsigned long long before = 0, all = 0;   // symbols of the chunks in front of this one, of all chunks
+            for (uint32_t j = (uint32_t)tid; j < n_win; j += kSlowThreads) {
+                const uint32_t x = cnt[j];
+                all += x;
+                if (j < it.k) before += x;
+            }
+            before = block_sum64(before, tmp64);
+            all = block_sum64(all, tmp64);
+            const uint32_t lo = it.k * kSeqChunk < len ? it.k * kSeqChunk : len, hi = lo + kSeqChunk < len ? lo + kSeqChunk : len;
+            uint32_t wave_off;
+            (void)expand_count(T, A, start, len, lo, hi, tmp, &wave_off);
+            expand_write(T, A, start, len, lo, hi, W.scratch + W.slow[ei].xoff + before, wave_off);
+            if (tid == 0 && it.k == 0) {
+                W.slow[ei].pad = (uint32_t)all;
+                W.slow[ei].win0 = win0 | kEntryExpanded;
+            }
+            continue;
+        }
+        if (pass) {   // second pass: the windows of the pre-tokens that were expanded, one item each
             if (!(win0 & kEntryExpanded)) continue;
             const uint32_t L = W.slow[ei].pad;
             if ((uint64_t)it.k * (uint64_t)kWin >= (uint64_t)L) continue;
-            const uint8_t* xs = W.scratch + start;
+            const uint8_t* xs = W.scratch + W.slow[ei].xoff;
             total = window_work(T, W, H, xs, L, it.k, img, live, xs, xs + (((uint64_t)L + 31ull) & ~15ull), ei, first);
             if (tid == 0 && total) {
                 atomicAdd(&W.slow[ei].count, total);
@@ -2318,30 +2414,26 @@ __global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables 
             total = window_work(T, W, H, A.text + start, len, it.k, img, live, A.text, A.text + A.n_bytes, ei, first);
             if (tid == 0 && it.k == 0) W.slow[ei].pad = len;   // its symbols
         } else {
-            if (it.k != 0) continue;   // a pre-token with invalid UTF-8: ONE item expands it
-            // symbols: one per byte, EF BF BD for a byte that is not valid UTF-8 (state_machine.go:36), written out
-            // to the scratch; every wave takes one contiguous range of the bytes, 64 at a time (order by ballots)
-            GlobalSrc gs{A.text, (int64_t)start, (int64_t)(start + len)};
-            const uint32_t lane = (uint32_t)lane_id(), wave = (uint32_t)wave_id();
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const uint32_t bw = ((len + kSlowThreads - 1) / kSlowThreads) * 64u;
-            const uint32_t b0 = wave * bw < len ? wave * bw : len;
-            const uint32_t b1 = b0 + bw < len ? b0 + bw : len;
-            uint32_t nsym = 0;
-            for (uint32_t base = b0; base < b1; base += 64) {
-                const uint32_t q = base + lane;
-                const bool in = q < b1;
-                const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
-                nsym += (uint32_t)__popcll(__ballot(in)) + 2u * (uint32_t)__popcll(__ballot(inv));
+            if (spread) {   // every window item counts the symbols of its chunk of the bytes; the first one reserves the scratch
+                const uint32_t lo = it.k * kSeqChunk < len ? it.k * kSeqChunk : len, hi = lo + kSeqChunk < len ? lo + kSeqChunk : len;
+                uint32_t wave_off;
+                const uint32_t n_sym = expand_count(T, A, start, len, lo, hi, tmp, &wave_off);
+                if (tid == 0) {
+                    W.win_cnt[(win0 & kEntryWinMask) + it.k] = n_sym;
+                    if (it.k == 0) {
+                        const unsigned long long need = (3ull * len + 31ull) & ~15ull;   // (at most three symbols a byte)
+                        const unsigned long long so2 = atomicAdd(&W.status->scratch_used, need);
+                        if (so2 + need > W.scratch_cap) atomicOr(&W.status->flags, kOvfScratch);
+                        W.slow[ei].xoff = so2;
+                        atomicOr(&W.status->flags, kSeqPending);
+                        atomicAdd(&W.tile_extra[W.slow[ei].tile], 0u - 1u);   // (the one its stream item stands for; the second pass adds the tokens)
+                    }
+                }
+                continue;
             }
-            if (lane == 0) tmp[wave] = nsym;
-            __syncthreads();
-            uint32_t L = 0, so = 0;
-            for (uint32_t w2 = 0; w2 < (uint32_t)(kSlowThreads / 64); w2++) {
-                const uint32_t x = tmp[w2];
-                if (w2 < wave) so += x;
-                L += x;
-            }
+            if (it.k != 0) continue;   // a short one: ONE item expands it and works through its windows
+            uint32_t so = 0;
+            const uint32_t L = expand_count(T, A, start, len, 0, len, tmp, &so);
             if (tid == 0) {
                 const unsigned long long need = ((unsigned long long)L + 31ull) & ~15ull;
                 const unsigned long long so2 = atomicAdd(&W.status->scratch_used, need);
@@ -2351,34 +2443,12 @@ __global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables 
             __syncthreads();
             if (lvars[5] < 0) continue;   // (uniform) the host grows the scratch and runs the batch again
             uint8_t* xs = W.scratch + lvars[5];
-            uint32_t o = so;
-            for (uint32_t base = b0; base < b1; base += 64) {
-                const uint32_t q = base + lane;
-                const bool in = q < b1;
-                const bool inv = in && (byte_info(gs, (int64_t)(start + q), T.cls_stage1, T.cls_blocks) & I_INVALID);
-                const unsigned long long mi = __ballot(in), mv = __ballot(inv);
-                const uint32_t pos = o + (uint32_t)__popcll(mi & lt) + 2u * (uint32_t)__popcll(mv & lt);
-                if (inv) {
-                    xs[pos] = 0xEF; xs[pos + 1] = 0xBF; xs[pos + 2] = 0xBD;
-                } else if (in) {
-                    xs[pos] = A.text[start + q];
-                }
-                o += (uint32_t)__popcll(mi) + 2u * (uint32_t)__popcll(mv);
-            }
+            expand_write(T, A, start, len, 0, len, xs, so);
             __syncthreads();
             const uint32_t nw = (L + (uint32_t)kWin - 1) / (uint32_t)kWin;
-            if (nw > (uint32_t)kSeqInline && W.allow_giants) {
-                // many windows: left to the second pass, where every window is an item of its own (the host starts it)
-                if (tid == 0) {
-                    W.slow[ei].start = (uint64_t)lvars[5];
-                    W.slow[ei].win0 = win0 | kEntryExpanded;
-                    W.slow[ei].pad = L;
-                    atomicOr(&W.status->flags, kSeqPending);
-                }
-            } else
 #pragma unroll 1
             for (uint32_t kk = 0; kk < nw; kk++) total += window_work(T, W, H, xs, L, kk, img, live, xs, xs + (((uint64_t)L + 31ull) & ~15ull), ei, first);
-            if (tid == 0) W.slow[ei].pad = L;   // (the same value if it was left to the second pass)
+            if (tid == 0) W.slow[ei].pad = L;
         }
         if (tid == 0 && (total || it.k == 0)) {
             atomicAdd(&W.slow[ei].count, total);
@@ -3075,10 +3145,11 @@ hipError_t launch_status_out(const Workspace& W, Status* host_dst, hipStream_t s
 hipError_t launch_slow_second_pass(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream) {
     hipLaunchKernelGGL(status_and_kernel, dim3(1), dim3(1), 0, stream, W.status, ~(uint32_t)kSeqPending);
     L3_LAUNCH_CHECK();
-    uint64_t sgrid = W.slow_cap < L3_SLOW_GRID ? W.slow_cap : L3_SLOW_GRID;
-    if (W.slow_grid && W.slow_grid < sgrid) sgrid = W.slow_grid;
+    uint64_t sgrid = W.slow_cap < L3_SLOW_GRID ? W.slow_cap : L3_SLOW_GRID;   // (the whole grid: the host knows there is work)
     if (sgrid == 0) sgrid = 1;
-    hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A, 1);
+    hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A, 2);   // expansion
+    L3_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slow_kernel, dim3((uint32_t)sgrid), dim3(kSlowThreads), 0, stream, T, W, A, 1);   // windows
     L3_LAUNCH_CHECK();
     return hipSuccess;
 }
