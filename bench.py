@@ -39,6 +39,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s s
 BATCH_DOCS = 65536
 DOC_BYTES = 1024
 C5_DOCS = 67108864     # 64 GiB
+# kernels of one stream-ordered batch (launch_encode + the finish launch); rocprofv3 summaries hold others too (generators)
+PIPELINE_KERNELS = ("docs_kernel", "tile_kernel", "merge_kernel", "slow_kernel", "block_totals_kernel", "emit_kernel",
+                    "finish_kernel", "emit_generic_kernel", "status_out_kernel", "copy_runs_kernel")
 
 
 def parse_args():
@@ -52,6 +55,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-docs", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the strong-scaling leg over the whole C5 corpus that follows the C2 steps")
+    ap.add_argument("--c5-slice-batches", type=int, default=128, help="batches of the C5 leg generated and held in HBM at a time (8 GiB)")
     ap.add_argument("--master-port", type=int, default=0)
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="all ranks on GPU 0 with gloo collectives: exercises the N > 1 code path on a one-GPU box (not a measurement)")
@@ -86,6 +91,10 @@ def source_digest():
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+C4_NAMES = ["blanks", "tabs", "newline_blank", "digits", "one_letter", "apostrophe_s", "random_bytes", "invalid_sequences",
+            "begin_of_text_every_64", "all_specials", "near_misses", "unicode_mix", "ff_quarter", "bangs_newlines"]
 
 
 def b_alg(n_bytes, n_tok, n_docs):
@@ -266,6 +275,68 @@ def main():
     else:
         tot_tok, tot_bytes, tot_docs = n_tok_total, my_bytes, my_docs
 
+    # ---- C5, strong scaling (BASELINE configs[4]; the reference's only concurrent workload is benchmark_test.go:151-174): the
+    #      whole corpus of --c5-batches batches cut into `world` contiguous ranges; every rank generates its range ON its GPU in
+    #      slices of --c5-slice-batches batches (untimed) and encodes each slice back to back (timed: the sum over the slices)
+    c5 = None
+    if args.config == "c2" and not args.no_c5:
+        c5_batches = shard.corpus_batches("c5", rank, world, 0, args.c5_batches)
+        del d_text
+        torch.cuda.empty_cache()
+        slice_n = max(1, min(args.c5_slice_batches, len(c5_batches)))
+        d_slice = torch.empty(slice_n * n_bytes, dtype=torch.uint8, device="cuda")
+        c5_tok, c5_s, c5_gen_s = 0, 0.0, 0.0
+        ctx.set_profiling(False)
+        for s0 in range(0, len(c5_batches), slice_n):
+            part = c5_batches[s0:s0 + slice_n]
+            g1 = time.perf_counter()
+            for i, b in enumerate(part):
+                corpora.english_device(d_slice[i * n_bytes:(i + 1) * n_bytes], b * n_docs, n_docs, DOC_BYTES)
+            torch.cuda.synchronize()
+            c5_gen_s += time.perf_counter() - g1
+            sargs = [(ctx.h, C.c_void_p(d_slice.data_ptr() + i * n_bytes), C.c_uint64(n_bytes), C.c_void_p(d_off.data_ptr()), C.c_uint64(n_docs),
+                      C.c_uint32(flags), C.c_void_p(outs[i & 1][0].data_ptr()), C.c_uint64(out_cap), C.c_void_p(outs[i & 1][1].data_ptr()),
+                      None, C.byref(ticket)) for i in range(len(part))]
+            e0 = time.perf_counter()
+            prev = None
+            for a in sargs:
+                rc = submit_fn(*a)
+                if rc != capi.L3_OK:
+                    raise RuntimeError("l3_encode_submit failed: %d" % rc)
+                t = ticket.value
+                if prev is not None:
+                    c5_tok += wait(prev)
+                prev = t
+            if prev is not None:
+                c5_tok += wait(prev)
+            torch.cuda.synchronize()
+            c5_s += time.perf_counter() - e0
+        del d_slice
+        c5_docs = len(c5_batches) * n_docs
+        if dist is not None:
+            _tb, _db, (c5_tok_all, c5_docs_all) = shard.gather_counts(dist, c5_tok, c5_docs, device=coll_dev)
+            t = torch.tensor([c5_s, c5_gen_s], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c5_s, c5_gen_s = float(t[0].item()), float(t[1].item())
+        else:
+            c5_tok_all, c5_docs_all = c5_tok, c5_docs
+        c5_bytes = c5_docs_all * DOC_BYTES
+        c5 = {"corpus_bytes": c5_bytes, "docs": c5_docs_all, "batches_per_gpu": len(c5_batches), "ms_total": c5_s * 1e3,
+              "ms_per_batch": c5_s * 1e3 / max(len(c5_batches), 1), "tokens": c5_tok_all, "tokens_per_s": c5_tok_all / c5_s if c5_s > 0 else None,
+              "input_gb_per_s": c5_bytes / c5_s / 1e9 if c5_s > 0 else None,
+              "frac": (b_alg(c5_bytes, c5_tok_all, c5_docs_all) / c5_s / 1e9 / (HBM_PEAK_GBS * world)) if c5_s > 0 else None,
+              "frac_note": "algorithmic bytes of the whole corpus / slowest rank's encode wall time / (n_gpus x 8 TB/s)",
+              "generation_s": c5_gen_s, "scaling": "strong", "n_gpus": world,
+              "n_ranks_seen_by_rccl": (world if (dist is not None and not args.rehearse_one_gpu) else (0 if dist is None else "gloo rehearsal")),
+              "note": "every rank generates its contiguous range of the corpus on its GPU, %d batches (%.0f GiB) at a time, untimed, and "
+                      "encodes each slice back to back through l3_encode_submit / l3_encode_wait; ms_total is the slowest rank's sum "
+                      "over its slices" % (slice_n, slice_n * n_bytes / 2 ** 30)}
+        d_text = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")      # (the legs below want rank 0's first batch again)
+        corpora.english_device(d_text, my_batches[0] * n_docs, n_docs, DOC_BYTES)
+        base_ptr = d_text.data_ptr()
+        all_args = [submit_args(0)]
+        torch.cuda.synchronize()
+
     if rank == 0:
         ms_per_step = dt / steps * 1e3
         value = tot_tok / dt
@@ -298,6 +369,7 @@ def main():
             "kernel_ms": kern, "kernel_ms_note": "per-kernel breakdown from an untimed pass over the same batches with events between all kernels",
             "kernel_ms_timed": {"docs": kern_timed["docs"], "tile": kern_timed["tile"], "total": kern_timed["total"]},
             "deferred_pretokens_last_batch": {"short": counters["short_pretokens"], "slow": counters["slow_pretokens"]},
+            **({"c5_strong": c5} if c5 is not None else {}),
             # frac: algorithmic bytes / (first kernel start -> last kernel end) / peak, as SURVEY 8(d) defines it
             "roofline": {"bound": "hbm", "achieved": pipeline, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pipeline / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": ba, "kernels_ms_per_launch": t_kernels,
@@ -312,7 +384,9 @@ def main():
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_summary.json")))[-1]
             summ = json.load(open(pm))
             if summ.get("source_digest") == source_digest():
-                result["roofline"]["traffic"] = sum(k["hbm_bytes_per_launch_corrected"] for k in summ["kernels"].values())
+                # (only what launch_encode and the hand-over launch: the corpus generator is not part of a step)
+                result["roofline"]["traffic"] = sum(k["hbm_bytes_per_launch_corrected"] for name, k in summ["kernels"].items()
+                                                    if name in PIPELINE_KERNELS)
                 result["roofline"]["traffic_source"] = os.path.relpath(pm, ROOT)
                 result["roofline"]["dominant"]["traffic"] = summ["kernels"].get(dom + "_kernel", {}).get("hbm_bytes_per_launch_corrected")
             else:
@@ -331,6 +405,16 @@ def main():
                 docs4 = corpora.pathological(1 << 20)
                 text4, off4 = capi.pack_docs(docs4)
                 other["c4_batch"], _ = time_resident(ctx, torch, capi, text4, off4, steps=3, warmup=1)
+                per_doc = []
+                for name, d in zip(C4_NAMES, docs4):     # every document of the batch on its own
+                    t, o = capi.pack_docs([d])
+                    r1, _ = time_resident(ctx, torch, capi, t, o, steps=2, warmup=1)
+                    cn = ctx.last_counters()
+                    per_doc.append({"doc": name, "bytes": len(d), "tokens": r1["tokens"], "kernels_ms": r1["kernels_ms"],
+                                    "slow_ms": r1["kernel_ms"]["slow"], "emit_ms": r1["kernel_ms"]["emit"], "host_passes_ms": r1["kernel_ms"].get("host_passes", 0.0),
+                                    "tile_ms": r1["kernel_ms"]["tile"], "merge_ms": r1["kernel_ms"]["merge"],
+                                    "window_items": cn["window_items"], "giant_symbols": cn["giant_symbols"]})
+                other["c4_batch"]["per_doc"] = per_doc
                 for name, d in (("c4_1MiB_one_letter", b"a" * (1 << 20)), ("c4_1MiB_invalid_bytes", b"\xff" * (1 << 20))):
                     t, o = capi.pack_docs([d])
                     other[name], _ = time_resident(ctx, torch, capi, t, o, steps=3, warmup=1)
@@ -340,9 +424,10 @@ def main():
             side = {}
             try:
                 # f-2: decode of this rank's last batch of ids (host-pointer call; the figure is the kernels' time by events)
-                wait(submit(steps - 1))
+                last_i = steps - 1 if c5 is None else 0
+                wait(submit(last_i))
                 torch.cuda.synchronize()
-                o, oo = outs[(steps - 1) & 1]
+                o, oo = outs[last_i & 1]
                 h_off = oo.cpu().numpy().astype(np.uint64)
                 h_ids = o[:int(h_off[-1])].cpu().numpy()
                 ctx.set_profiling(1)

@@ -126,14 +126,14 @@ int l3_host_free(l3_ctx* ctx, void* p);
 
 /* Measurement support (no counterpart in the reference): when enabled, HIP events are recorded on the
  * launch stream between the kernels of every encode call; l3_last_timings() returns the milliseconds of
- * the last call: [0] validate+docs, [1] tile kernel, [2] merge kernel, [3] slow kernel, [4] scan, [5] emit,
- * [6] first kernel start -> last kernel end, [7] (cap >= 8) the kernels of the last l3_decode_batch.  Returns the number of
- * values written.  enabled = 2: only the events the
- * roofline figures need (around the tile kernel, and first start / last end): [0], [1] and [6] are filled in, the others 0;
+ * the last call: [0] validate+docs, [1] tile kernel, [2] merge kernel, [3] slow kernel, [4] block totals, [5] the host-driven
+ * passes of a batch with very long pre-tokens (0 otherwise), [6] emit, [7] first kernel start -> last kernel end, [8] (cap >= 9)
+ * the kernels of the last l3_decode_batch.  Returns the number of values written.  enabled = 2: only the events the roofline
+ * figures need (around the tile kernel, and first start / last end): [0], [1] and [7] are filled in, the others 0;
  * every event between two kernels keeps the second from starting early, four of them cost a 64 MiB batch about 3 %. */
 int l3_set_profiling(l3_ctx* ctx, int enabled);
 int l3_last_timings(l3_ctx* ctx, float* ms, int cap);
-/* the same seven values summed over the *calls profiled encode calls since l3_set_profiling() was last called (every
+/* the same eight values summed over the *calls profiled encode calls since l3_set_profiling() was last called (every
  * call of it resets the sums), so a benchmark loop need not ask after every step */
 int l3_timing_totals(l3_ctx* ctx, double* ms, int cap, uint64_t* calls);
 /* counters of the last encode call: [0] tiles, [1] deferred (slow) pre-tokens, [2] tokens of all

@@ -261,16 +261,16 @@ class Context:
         self.lib.l3_set_profiling(self.h, int(on))
 
     def last_timings(self):
-        a = np.zeros(8, dtype=np.float32)
-        self.lib.l3_last_timings(self.h, a.ctypes.data, 8)
-        return dict(zip(["docs", "tile", "merge", "slow", "scan", "emit", "total", "decode"], a.tolist()))
+        a = np.zeros(9, dtype=np.float32)
+        self.lib.l3_last_timings(self.h, a.ctypes.data, 9)
+        return dict(zip(["docs", "tile", "merge", "slow", "scan", "host_passes", "emit", "total", "decode"], a.tolist()))
 
     def timing_totals(self):
-        """(sums of the seven timings over the profiled calls since set_profiling, number of those calls)"""
-        a = np.zeros(7, dtype=np.float64)
+        """(sums of the eight timings over the profiled calls since set_profiling, number of those calls)"""
+        a = np.zeros(8, dtype=np.float64)
         n = C.c_uint64(0)
-        self.lib.l3_timing_totals(self.h, a.ctypes.data, 7, C.byref(n))
-        return dict(zip(["docs", "tile", "merge", "slow", "scan", "emit", "total"], a.tolist())), int(n.value)
+        self.lib.l3_timing_totals(self.h, a.ctypes.data, 8, C.byref(n))
+        return dict(zip(["docs", "tile", "merge", "slow", "scan", "host_passes", "emit", "total"], a.tolist())), int(n.value)
 
     def last_counters(self):
         a = np.zeros(8, dtype=np.uint64)

@@ -301,7 +301,7 @@ int rerun_emit(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t s
     return mark_batch_end(c, stream);
 }
 
-// Milliseconds between the events of one profiled call: [docs, tile, merge, slow, scan, emit, first start -> last end]; in
+// Milliseconds between the events of one profiled call: [docs, tile, merge, slow, scan, host-driven passes, emit, first start -> last end]; in
 // light mode only docs, tile and the total exist (the others are 0).
 int event_times(l3_ctx* c, hipEvent_t* ev, bool light, float* ms) {
     for (int i = 0; i < kEvCount; i++) ms[i] = 0;
@@ -346,9 +346,10 @@ int run_giants(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t s
     }
     if (!done) { c->err = "grid-wide merge did not finish"; return L3_E_HIP; }
     HIPCHK(c, launch_giants_store(W, n_syms, c->w_giant.p, stream));
+    if (c->profiling && !c->profiling_light) HIPCHK(c, hipEventRecord(c->ev[kEvHost], stream));   // up to here: the host-driven passes
     HIPCHK(c, hipMemsetAsync(&W.status->flags, 0, 8, stream));   // flags (kGiantPending) and generic_tiles
     HIPCHK(c, launch_encode_tail(W, A, stream));
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[kEvEmit], stream));   // the "emit" figure then holds the grid-wide merge too
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[kEvEmit], stream));
     HIPCHK(c, launch_status_out(W, c->h_status, stream));
     HIPCHK(c, hipStreamSynchronize(stream));
     return L3_OK;
@@ -393,6 +394,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
             c->status_dirty = false;
         }
         if (redo_tail && !(c->h_status->flags & (kFatalFlags | kRetryFlags))) {
+            if (c->profiling && !c->profiling_light) HIPCHK(c, hipEventRecord(c->ev[kEvHost], stream));
             HIPCHK(c, launch_encode_tail(W, A, stream));
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[kEvEmit], stream));
             HIPCHK(c, launch_status_out(W, c->h_status, stream));

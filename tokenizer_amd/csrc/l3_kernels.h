@@ -202,7 +202,10 @@ struct EncodeArgs {
 
 __host__ __device__ inline uint64_t num_tiles(uint64_t n_bytes) { return n_bytes == 0 ? 1 : (n_bytes + kTile - 1) / kTile; }
 
-enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvEmit, kEvCount };
+// kEvHost: right behind kEvScan in an ordinary batch; a batch with host-driven passes (long pre-tokens with invalid UTF-8, the
+// grid-wide merge) records it again in front of the tail of the pipeline it then runs, so that the interval kEvScan -> kEvHost
+// holds those passes and kEvHost -> kEvEmit the final scatter alone.
+enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvHost, kEvEmit, kEvCount };
 
 // Enqueue the encode pipeline on `stream`; nothing is synchronised.  `ev` (optional, kEvCount
 // events) are recorded between the kernels.  `emit_only` re-runs just the final scatter (after

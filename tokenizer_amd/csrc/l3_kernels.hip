@@ -3202,6 +3202,7 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
         hipError_t e2_ = launch_totals_scan(W, A, stream);
         if (e2_ != hipSuccess) return e2_;
         L3_EV(kEvScan);
+        L3_EV(kEvHost);
     }
     hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)((n_tiles + kTileThreads / 64 - 1) / (kTileThreads / 64))), dim3(kTileThreads), 0, stream, W, A, (uint32_t)n_tiles);
     L3_LAUNCH_CHECK();
