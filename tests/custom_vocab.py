@@ -17,10 +17,13 @@ import numpy as np
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tokenizer_amd", "data")
 
 
-def truncated_vocabulary(n_tokens, full_merges=False):
+def truncated_vocabulary(n_tokens, full_merges=False, shuffle_seed=None, duplicates=0):
     """Returns (vocab_file_bytes, merges_file_bytes, n_merges_kept).  full_merges: the shipped merges file unchanged (the
     reference loads that too: pairs naming unknown ids are skipped, decoder.go:61-63, and a rule whose product is not in the
-    vocabulary produces nothing, bpe.go:157-161)."""
+    vocabulary produces nothing, bpe.go:157-161).  shuffle_seed: the kept rules in a random order -- for the reference a rule's
+    rank is its index in the file and nothing else (decoder.go:41-71), so this is valid data for a different tokenizer, one
+    whose pairs are NOT grouped by ascending product id.  duplicates: that many rules are repeated further down the list (the
+    later rank counts: the map entry is overwritten)."""
     vraw = base64.b64decode(open(os.path.join(DATA, "vocab_base64.txt"), "rb").read())
     mraw = base64.b64decode(open(os.path.join(DATA, "merges_binary.txt"), "rb").read())
     toks = [t for t in vraw.split(b"\n") if t]
@@ -38,6 +41,15 @@ def truncated_vocabulary(n_tokens, full_merges=False):
         a, b = int(ids[k]), int(ids[k + 1])
         if a < n_tokens and b < n_tokens and index[toks[a] + toks[b]] < n_tokens:
             kept += [a, b]
+    if shuffle_seed is not None:
+        rng = np.random.default_rng(shuffle_seed)
+        pairs = np.asarray(kept, dtype=np.int64).reshape(-1, 2)
+        pairs = pairs[rng.permutation(pairs.shape[0])]
+        if duplicates:
+            again = pairs[rng.integers(0, pairs.shape[0] // 2, duplicates)]
+            pos = np.sort(rng.integers(pairs.shape[0] // 2, pairs.shape[0], duplicates))
+            pairs = np.insert(pairs, pos, again, axis=0)
+        kept = pairs.reshape(-1).tolist()
     kb = ((np.asarray(kept, dtype=np.int64)[:, None] >> np.arange(16, -1, -1)) & 1).astype(np.uint8).reshape(-1)
     packed = np.packbits(kb).tobytes()                                             # zero bits pad the last byte
     return base64.b64encode(b"\n".join(toks[:n_tokens]) + b"\n"), base64.b64encode(packed), len(kept) // 2

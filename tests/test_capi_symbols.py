@@ -38,11 +38,13 @@ def test_create_rejects_bad_data_without_gpu():
         bits = ((ids[:, None] >> np.arange(16, -1, -1)) & 1).astype(np.uint8).reshape(-1)
         return base64.b64encode(np.packbits(bits).tobytes())
 
-    # rules out of rank order (products must not decrease: 'in' = 258 before the rule of token 256)
-    bad = pack([(72, 77), (220, 220)])
-    rc = lib.l3_create(vocab, len(vocab), bad, len(bad), 0, C.byref(h))
-    assert rc == capi.L3_E_DATA and not h.value
-    assert b"ascending product id" in lib.l3_last_error(None)
+    # rules whose products are not in ascending order ('in' = 258 before the rule of token 256): valid for the reference (a
+    # rule's rank is its index, decoder.go:41-71) and served in rank mode here, so the call gets as far as looking for a GPU
+    unordered = pack([(72, 77), (220, 220)])
+    rc = lib.l3_create(vocab, len(vocab), unordered, len(unordered), 0, C.byref(h))
+    assert rc in (capi.L3_E_NO_DEVICE, capi.L3_OK)
+    if rc == capi.L3_OK:
+        lib.l3_destroy(h)
     # pairs naming ids beyond the token list are skipped as the reference does (decoder.go:61-63): valid data, so the
     # call gets as far as looking for a GPU
     skipped = base64.b64encode(b"\xff" * 34)

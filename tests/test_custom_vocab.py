@@ -120,3 +120,66 @@ def test_gpu_custom_vocabulary_parity(small_ctx, small_oracle):
     ids = got_tok[:int(got_off[3])]
     out, out_off = ctx.decode_batch(ids, got_off[:4])
     assert out.tobytes() == o.decode(ids.tolist())
+
+
+# ---- merge lists the packed priority cannot express (rank mode, l3_common.h): rules in a random order, some repeated ----
+@pytest.fixture(scope="module")
+def shuffled_files():
+    v, m, n_merges = truncated_vocabulary(8000, shuffle_seed=11, duplicates=200)
+    assert n_merges > 10000
+    return v, m
+
+
+@pytest.fixture(scope="module")
+def shuffled_oracle(shuffled_files):
+    from tests.oracle import Oracle
+    return Oracle(*shuffled_files)
+
+
+def _shuffled_docs():
+    rng = random.Random(21)
+    docs = [corpus.random_doc(rng) for _ in range(1500)]
+    docs += [b"x" * 700, b"abcabcabc" * 300, ("слово " * 400).encode(), b"The quick brown fox jumps over the lazy dog. " * 200,
+             b"a" * 40000, b"", b"\xff\xfe" * 50 + b"tail"]
+    return docs
+
+
+def test_rank_mode_host_merge_equals_the_oracle(shuffled_files, shuffled_oracle, oracle):
+    """The host build of the merge loops (the code the kernels share) on a merge list in random order against the oracle's
+    heap: the greedy order follows the rank, whatever the ranks are."""
+    from tests.hostshim import HostShim
+    h = HostShim(*shuffled_files)
+    rng = random.Random(5)
+    words = set()
+    for d in _shuffled_docs()[:400]:
+        for w in d.replace(b"\n", b" ").split(b" "):
+            if 1 <= len(w) <= 120 and b"<|" not in w:      # (special-token text: matched before BPE, not by it)
+                words.add(w)
+    words = sorted(words)[:3000] + [b"a" * 300, b"abcabcabc" * 30, bytes(rng.randrange(97, 123) for _ in range(500))]
+    differs = 0
+    for w in words:
+        if h.vocab_lookup(w) >= 0:
+            continue
+        exp = shuffled_oracle.bpe_raw(w)
+        assert h.bpe(w) == exp, w
+        assert h.bpe_rounds(w)[0] == exp, w
+        assert h.bpe_pieces(w)[0] == exp, w
+        differs += exp != oracle.bpe_raw(w)
+    assert differs > 100      # (it IS another tokenizer than the shipped one)
+
+
+@pytest.mark.gpu
+def test_rank_mode_gpu_equals_the_oracle(shuffled_files, shuffled_oracle):
+    """WithDataFiles / WithDataLoader with a merge list in random order with repeated pairs: the GPU path (rank mode) against
+    the oracle built from the same files, all merge paths (lane, wave, window, grid-wide)."""
+    from tokenizer_amd import capi
+    ctx = capi.Context(device=0, vocab=shuffled_files[0], merges=shuffled_files[1])
+    try:
+        docs = _shuffled_docs()
+        text, off = capi.pack_docs(docs)
+        for bos, eos in ((True, True), (False, False)):
+            tok, toff = ctx.encode_batch(text, off, bos, eos)
+            exp_tok, exp_off = shuffled_oracle.encode_batch(text, off, bos, eos, threads=8)
+            assert np.array_equal(toff, exp_off) and np.array_equal(tok, exp_tok)
+    finally:
+        ctx.close()

@@ -78,7 +78,7 @@ struct l3_ctx {
     int device = 0;
     HostTables H;
     Tables T{};
-    DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes, t_prefix2, t_bloom;
+    DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes, t_prefix2, t_bloom, t_rankm;
     // The status word is zero between two calls: the kernel that hands it to the host (status_out_kernel) clears it, in
     // stream order behind the batch.  Calls on DIFFERENT streams are ordered by an event the context owns, recorded behind
     // every batch: the caller's stream handle is never kept, it may be destroyed between two calls.
@@ -162,6 +162,7 @@ int upload_tables(l3_ctx* c) {
     if ((rc = upload(c, c->t_tokbytes, H.tok_bytes.data(), H.tok_bytes.size()))) return rc;
     if ((rc = upload(c, c->t_prefix2, H.prefix2.data(), H.prefix2.size()))) return rc;
     if ((rc = upload(c, c->t_bloom, H.prefix_bloom.data(), H.prefix_bloom.size()))) return rc;
+    if (!H.rank_merged.empty() && (rc = upload(c, c->t_rankm, H.rank_merged.data(), H.rank_merged.size()))) return rc;
     Tables& T = c->T;
     T.cls_stage1 = c->t_cls1.as<uint16_t>();
     T.cls_blocks = c->t_clsb.as<uint8_t>();
@@ -173,6 +174,8 @@ int upload_tables(l3_ctx* c) {
     T.special_id = c->t_special.as<int32_t>();
     T.prefix2 = c->t_prefix2.as<uint32_t>();
     T.prefix_bloom = c->t_bloom.as<uint32_t>();
+    T.rank_merged = H.rank_merged.empty() ? nullptr : c->t_rankm.as<uint32_t>();
+    T.rank_count = (uint32_t)H.rank_merged.size();
     T.pair_log2 = H.pair_log2;
     T.vocab_log2 = H.vocab_log2;
     T.bloom_log2 = H.bloom_log2;

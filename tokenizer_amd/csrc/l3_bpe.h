@@ -117,7 +117,7 @@ L3_HD void merge_span(const Tables& t, Sym& sym, Pr& pr, int s, int e) {
         while (r < e && sym[r] < 0) r++;   // next live symbol after the pair (r == e: none)
         int l = bp - 1;
         while (l >= s && sym[l] < 0) l--;  // previous live symbol (l < s: none)
-        const uint32_t m = prio_merged_id(best);
+        const uint32_t m = prio_merged_id(t, best);
         sym[bp] = (int32_t)m;
         sym[q] = -1;
         pr[q] = kNoPrio;

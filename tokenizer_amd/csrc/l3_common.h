@@ -19,13 +19,14 @@ constexpr int kMaxTokenBytes = 128; // longest vocabulary entry (raw bytes)
 
 // ---- merge priority ---------------------------------------------------------------------------
 // The reference orders candidate merges by rank = 1-based index of the pair in the merge file
-// (internal/vocabulary/decoder.go:67, bpe.go:126).  In that file all pairs producing the same
+// (internal/vocabulary/decoder.go:67, bpe.go:126).  In the shipped file all pairs producing the same
 // token are consecutive and product ids never decrease, so
 //     prio = (merged_id << 7) | index_of_pair_within_its_product      (24 bits)
-// is order-isomorphic to rank AND carries the merged id; the table builder verifies both facts
-// and refuses data for which they do not hold.
+// is order-isomorphic to rank AND carries the merged id: one probe per new pair, nothing else to look up.  The table
+// builder checks both facts.  Merge data for which they do not hold (any pair list is valid for the reference: rank is just
+// the index, decoder.go:41-71) is served in RANK MODE: prio = the pair's index among the kept rules (< 2^24), and the merged
+// id comes from Tables::rank_merged[prio] -- one more (cached) load per applied merge.
 constexpr uint32_t kNoPrio = 0xFFFFFFFFu;
-L3_HD uint32_t prio_merged_id(uint32_t prio) { return prio >> 7; }
 
 // ---- pair table: (idA,idB) -> prio, two-choice (cuckoo) hashing over 16-byte buckets of two slots ---------
 // slot = key34 << 24 | prio24 ; empty = ~0.  key34 = idA << 17 | idB.  Every key lives in one of its two
@@ -153,10 +154,18 @@ struct Tables {
     const int32_t* special_id;    // [256] canonical special index -> token id (0 = not a token)
     const uint32_t* prefix2;      // [kPrefix2Words] bit (a << 8 | b): some vocabulary entry starts with the bytes a b
     const uint32_t* prefix_bloom; // [1 << (bloom_log2 - 5)] one-hash Bloom filter of the prefixes of 3 and more bytes
+    const uint32_t* rank_merged;  // rank mode only (else nullptr): merged id of every prio
     uint32_t pair_log2;
     uint32_t vocab_log2;
     uint32_t bloom_log2;
+    uint32_t rank_count;          // rank mode: entries of rank_merged
 };
+
+// token id a merge of priority `prio` produces.  Callers may pass kNoPrio (lanes without a pair compute along and drop
+// the answer): packed mode is plain arithmetic, rank mode clamps the index so that the load stays inside the table.
+L3_HD uint32_t prio_merged_id(const Tables& t, uint32_t prio) {
+    return t.rank_merged ? t.rank_merged[prio < t.rank_count ? prio : 0u] : prio >> 7;
+}
 
 // canonical special index: 0..7 = the named tokens in regex order (special.go:12), 8+k = reserved_k
 constexpr int kSpecialNamed = 8;

@@ -228,13 +228,13 @@ __global__ __launch_bounds__(kGiantThreads) void giant_theta_kernel(Tables T, Wo
         const unsigned long long key = ((unsigned long long)p << 32) | i;
         const bool covered = (i >= 1u && (sm1 & kSelBit) && pm1 <= p) || ((sp1 & kSelBit) && pp1 < p);
         if (valid && !sel && !covered) th = key < th ? key : th;
-        const uint32_t m = prio_merged_id(p);
+        const uint32_t m = prio_merged_id(T, p);
         const bool hasl = sel && i >= 1u && !(s0 & kSegBit);              // a left neighbour in the same piece
         const bool hasr = sel && i + 2u < n && !(sp2 & kSegBit);          // a symbol behind the pair in the same piece
         uint32_t lsym = (uint32_t)(sm1 & kIdMask);
-        if (i >= 2u && (sm2 & kSelBit) && pm2 <= p) lsym = prio_merged_id(pm2);
+        if (i >= 2u && (sm2 & kSelBit) && pm2 <= p) lsym = prio_merged_id(T, pm2);
         uint32_t rsym = (uint32_t)(sp2 & kIdMask);
-        if ((sp2 & kSelBit) && pp2 < p) rsym = prio_merged_id(pp2);
+        if ((sp2 & kSelBit) && pp2 < p) rsym = prio_merged_id(T, pp2);
         const uint32_t a1 = hasl ? lsym : 0u, b1 = hasl ? m : 0u;   // idle lanes probe (0, 0)
         const uint32_t a2 = hasr ? m : 0u, b2 = hasr ? rsym : 0u;
         uint32_t r1, r2;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kGiantThreads) void giant_count_kernel(Workspace W,
 }
 
 // ---- phase 5: apply the members of S below theta, compacting into the other arrays
-__global__ __launch_bounds__(kGiantThreads) void giant_apply_kernel(Workspace W, Flat F) {
+__global__ __launch_bounds__(kGiantThreads) void giant_apply_kernel(Tables T, Workspace W, Flat F) {
     GiantState& st = *W.gstate;
     if (finished(st)) return;
     const uint32_t n = st.n, cur = st.round & 1u;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kGiantThreads) void giant_apply_kernel(Workspace W,
             const uint32_t p = pa[i];
             const int32_t x = sa[i];
             const bool applied = (x & kSelBit) && (((unsigned long long)p << 32) | i) < th;
-            sb[j] = applied ? (int32_t)(prio_merged_id(p) | (uint32_t)kDirtyBit | (uint32_t)(x & kSegBit)) : (x & kKeepMask);
+            sb[j] = applied ? (int32_t)(prio_merged_id(T, p) | (uint32_t)kDirtyBit | (uint32_t)(x & kSegBit)) : (x & kKeepMask);
             pb[j] = p;
             ob[j] = oa[i];
         }
@@ -418,7 +418,7 @@ hipError_t launch_giants_rounds(const Tables& T, const Workspace& W, uint64_t n_
         hipLaunchKernelGGL(giant_select_kernel, dim3(kGiantGrid), dim3(kGiantThreads), 0, stream, W, F);
         hipLaunchKernelGGL(giant_theta_kernel, dim3(kGiantGrid), dim3(kGiantThreads), 0, stream, T, W, F);
         hipLaunchKernelGGL(giant_count_kernel, dim3(kGiantGrid), dim3(kGiantThreads), 0, stream, W, F);
-        hipLaunchKernelGGL(giant_apply_kernel, dim3(kGiantGrid), dim3(kGiantThreads), 0, stream, W, F);
+        hipLaunchKernelGGL(giant_apply_kernel, dim3(kGiantGrid), dim3(kGiantThreads), 0, stream, T, W, F);
         hipLaunchKernelGGL(giant_reprobe_kernel, dim3(kGiantGrid), dim3(kGiantThreads), 0, stream, T, W, F);
         hipLaunchKernelGGL(giant_next_kernel, dim3(1), dim3(1), 0, stream, W);
         L3_LAUNCH_CHECK();

@@ -52,6 +52,8 @@ void* l3t_create(const void* vocab, size_t vlen, const void* merges, size_t mlen
     h->T.vocab_log2 = h->H.vocab_log2;
     h->T.prefix2 = h->H.prefix2.data();
     h->T.prefix_bloom = h->H.prefix_bloom.data();
+    h->T.rank_merged = h->H.rank_merged.empty() ? nullptr : h->H.rank_merged.data();
+    h->T.rank_count = (uint32_t)h->H.rank_merged.size();
     h->T.bloom_log2 = h->H.bloom_log2;
     return h;
 }
@@ -159,7 +161,7 @@ void l3t_probe_stats(void* hp, const uint8_t* bytes, int64_t n, int64_t* out) {
         int q = bp + 1; while (sym[q] < 0) q++;
         int r = q + 1; while (r < (int)n && sym[r] < 0) r++;
         int l = bp - 1; while (l >= 0 && sym[l] < 0) l--;
-        uint32_t m = prio_merged_id(best);
+        uint32_t m = prio_merged_id(T, best);
         sym[bp] = (int32_t)m; sym[q] = -1; pr[q] = kNoPrio;
         pr[bp] = r < (int)n ? probe(m, (uint32_t)sym[r]) : kNoPrio;
         if (l >= 0) pr[l] = probe((uint32_t)sym[l], m);
@@ -209,15 +211,15 @@ int64_t l3t_bpe_rounds(void* hp, const uint8_t* bytes, int64_t n0, int32_t* out,
                 if (!covered && key < th) th = key;
                 continue;
             }
-            uint32_t m = prio_merged_id(p), v = kNoPrio;
+            uint32_t m = prio_merged_id(T, p), v = kNoPrio;
             if (i >= 1) {
                 uint32_t lsym = (uint32_t)sa[i - 1];
-                if (i >= 2 && sel[i - 2] && pa[i - 2] <= p) lsym = prio_merged_id(pa[i - 2]);
+                if (i >= 2 && sel[i - 2] && pa[i - 2] <= p) lsym = prio_merged_id(T, pa[i - 2]);
                 v = pair_prio(T, lsym, m);
             }
             if (i + 2 < n) {
                 uint32_t rsym = (uint32_t)sa[i + 2];
-                if (sel[i + 2] && pa[i + 2] < p) rsym = prio_merged_id(pa[i + 2]);
+                if (sel[i + 2] && pa[i + 2] < p) rsym = prio_merged_id(T, pa[i + 2]);
                 uint32_t v2 = pair_prio(T, m, rsym);
                 v = v2 < v ? v2 : v;
             }
@@ -231,7 +233,7 @@ int64_t l3t_bpe_rounds(void* hp, const uint8_t* bytes, int64_t n0, int32_t* out,
             bool dead = i >= 1 && sel[i - 1] && ((((unsigned long long)pa[i - 1]) << 32) | (i - 1)) < th;
             if (dead) continue;
             bool applied = sel[i] && ((((unsigned long long)pa[i]) << 32) | i) < th;
-            sb.push_back(applied ? (int32_t)prio_merged_id(pa[i]) : sa[i]);
+            sb.push_back(applied ? (int32_t)prio_merged_id(T, pa[i]) : sa[i]);
             pb.push_back(pa[i]);
             dirty.push_back(applied ? 1 : 0);
         }

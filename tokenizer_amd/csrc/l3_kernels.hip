@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void lane_merge(const Tables& T, uint32_t* sy, uint32
 #pragma unroll
         for (int p = 0; p < S; p++) best = min(best, pq[p]);
         if (best == 0xFFFFFFFFu) return;
-        const uint32_t bp = best & 127u, m = best >> 14;        // prio24 >> 7 = merged id
+        const uint32_t bp = best & 127u, m = prio_merged_id(T, best >> 7);
         const uint32_t wb = sy[bp];
         const uint32_t q = (wb >> 17) & 127u, l = (wb >> 24) & 127u;
         const uint32_t r = (sy[q] >> 17) & 127u;
@@ -1487,13 +1487,13 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
                 key[k] = ((unsigned long long)p << 32) | i;
                 const bool covered = (i >= 1u && (sm1 & kSelBit) && pm1 <= p) || ((sp1 & kSelBit) && pp1 < p);
                 if (valid && !sel[k] && !covered) th = key[k] < th ? key[k] : th;
-                m[k] = prio_merged_id(p);
+                m[k] = prio_merged_id(T, p);
                 hasl[k] = sel[k] && i >= 1u;
                 hasr[k] = sel[k] && i + 2u < n;
                 uint32_t lsym = (uint32_t)(sm1 & kIdMask);
-                if (i >= 2u && (sm2 & kSelBit) && pm2 <= p) lsym = prio_merged_id(pm2);
+                if (i >= 2u && (sm2 & kSelBit) && pm2 <= p) lsym = prio_merged_id(T, pm2);
                 uint32_t rsym = (uint32_t)(sp2 & kIdMask);
-                if ((sp2 & kSelBit) && pp2 < p) rsym = prio_merged_id(pp2);
+                if ((sp2 & kSelBit) && pp2 < p) rsym = prio_merged_id(T, pp2);
                 const uint32_t a1 = hasl[k] ? lsym : 0u, b1 = hasl[k] ? m[k] : 0u;   // idle lanes probe (0, 0)
                 const uint32_t a2 = hasr[k] ? m[k] : 0u, b2 = hasr[k] ? rsym : 0u;
                 k1[k] = pair_key(a1, b1);
@@ -1545,7 +1545,7 @@ __device__ uint32_t merge_rounds(const Tables& T, int32_t*& sa, uint32_t*& pa, i
                 const uint32_t p = pa[i];
                 const int32_t x = sa[i];
                 const bool applied = (x & kSelBit) && (((unsigned long long)p << 32) | i) < th;
-                sb[j] = applied ? (int32_t)(prio_merged_id(p) | (uint32_t)kDirtyBit) : (x & kIdMask);
+                sb[j] = applied ? (int32_t)(prio_merged_id(T, p) | (uint32_t)kDirtyBit) : (x & kIdMask);
                 pb[j] = p;
             }
             j0 += (uint32_t)__popcll(lm);

@@ -188,15 +188,16 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
         T.byte_tok[b] = (uint8_t)it->second;
     }
 
-    // ---- merges: 17-bit id pairs, rank = pair index + 1
+    // ---- merges: 17-bit id pairs, rank = pair index + 1 (decoder.go:41-71: any pair list is valid, a later duplicate of a pair
+    //      overwrites the earlier one's rank)
     BitReader br{mbin.data(), mbin.size() * 8};
-    struct Rule { uint32_t a, b, merged, sub; };
+    struct Rule { uint32_t a, b, merged, prio; };
     std::vector<Rule> rules;
     rules.reserve(mbin.size() * 8 / 34 + 1);
+    bool grouped = true;   // all pairs of one product consecutive (<= 128 of them), product ids never decreasing: the packed priority
     {
-        std::unordered_map<uint64_t, int> seen;
+        std::unordered_map<uint64_t, size_t> seen;   // pair -> index in `rules`
         seen.reserve(1 << 19);
-        uint32_t last_merged = 0, sub = 0;
         bool tail = false;   // a rule whose product is not in the vocabulary has been seen
         while (br.has(34)) {
             uint32_t a = br.get(17), b = br.get(17);
@@ -213,14 +214,38 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
             }
             if (tail) { T.error = "a merge rule whose product is not in the vocabulary precedes productive rules (unsupported)"; return false; }
             if (it->second >= n_base) { T.error = "merge rule whose product is a special token"; return false; }
-            uint32_t m = (uint32_t)it->second;
-            if (!seen.emplace(pair_key(a, b), 1).second) { T.error = "duplicate merge rule"; return false; }
-            if (!rules.empty() && m < last_merged) { T.error = "merge rules are not grouped by ascending product id"; return false; }
-            sub = (!rules.empty() && m == last_merged) ? sub + 1 : 0;
-            if (sub >= 128) { T.error = "more than 128 merge rules for one product"; return false; }
-            last_merged = m;
-            rules.push_back(Rule{a, b, m, sub});
+            const uint32_t m = (uint32_t)it->second;
+            auto ins = seen.emplace(pair_key(a, b), rules.size());
+            if (!ins.second) {   // the pair again: the later rank counts.  The earlier rule becomes a hole in the list
+                rules[ins.first->second].merged = 0xFFFFFFFFu;
+                ins.first->second = rules.size();
+                grouped = false;
+            }
+            rules.push_back(Rule{a, b, m, 0});
         }
+    }
+    {
+        std::vector<Rule> kept;
+        kept.reserve(rules.size());
+        for (const Rule& r : rules) if (r.merged != 0xFFFFFFFFu) kept.push_back(r);
+        rules.swap(kept);
+    }
+    {
+        uint32_t last_merged = 0, sub = 0;
+        for (size_t k = 0; k < rules.size() && grouped; k++) {
+            const uint32_t m = rules[k].merged;
+            if (k && m < last_merged) grouped = false;
+            sub = (k && m == last_merged) ? sub + 1 : 0;
+            if (sub >= 128) grouped = false;
+            last_merged = m;
+            rules[k].prio = (m << 7) | sub;
+        }
+    }
+    T.rank_merged.clear();
+    if (!grouped) {   // rank mode (l3_common.h): prio = index among the kept rules, merged id by table
+        if (rules.size() >= (1u << 24)) { T.error = "more than 2^24 merge rules"; return false; }
+        T.rank_merged.resize(rules.size());
+        for (size_t k = 0; k < rules.size(); k++) { rules[k].prio = (uint32_t)k; T.rank_merged[k] = rules[k].merged; }
     }
     T.n_merges = (int)rules.size();
 
@@ -231,7 +256,7 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
     uint8_t tok_byte[256];  // id -> byte for ids 0..255
     for (int b = 0; b < 256; b++) tok_byte[T.byte_tok[b]] = (uint8_t)b;
     for (const Rule& r : rules)
-        if (r.a < 256 && r.b < 256) T.bytepair[((uint32_t)tok_byte[r.a] << 8) | tok_byte[r.b]] = (r.merged << 7) | r.sub;
+        if (r.a < 256 && r.b < 256) T.bytepair[((uint32_t)tok_byte[r.a] << 8) | tok_byte[r.b]] = r.prio;
 
     // ---- pair table: cuckoo placement into two-slot buckets
     uint64_t rng = 0x243F6A8885A308D3ull;
@@ -241,7 +266,7 @@ bool build_tables(const void* vocab_b64, size_t vocab_len, const void* merges_b6
         T.pair_buckets.assign(1ull << T.pair_log2, PairBucket{{kPairEmpty, kPairEmpty}});
         bool ok = true;
         for (const Rule& r : rules) {
-            uint64_t item = (pair_key(r.a, r.b) << 24) | ((r.merged << 7) | r.sub);
+            uint64_t item = (pair_key(r.a, r.b) << 24) | r.prio;
             bool placed = false;
             for (int kick = 0; kick < 1000 && !placed; kick++) {
                 uint32_t b[2];

@@ -27,6 +27,7 @@ struct HostTables {
     std::vector<uint32_t> prefix2;       // kPrefix2Words
     std::vector<uint32_t> prefix_bloom;  // 1 << (bloom_log2 - 5) words
     uint32_t bloom_log2 = 0;
+    std::vector<uint32_t> rank_merged;   // rank mode only (merge data whose pairs are not grouped by ascending product): merged id of every prio
     // raw bytes of every token id (0..128255) for Decode (tokenizer.go:339-354)
     std::vector<uint8_t> tok_bytes;
     std::vector<uint32_t> tok_off;  // n_tokens + 1
