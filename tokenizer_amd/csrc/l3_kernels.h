@@ -1,4 +1,4 @@
-// l3_kernels.h -- launch interface of the HIP kernels (l3_kernels.hip) used by the C ABI (l3_api.hip).
+// l3_kernels.h -- launch interface of the HIP kernels (l3_pipeline.hip and the stage units l3_tile / l3_merge / l3_slow / l3_emit / l3_decode .hip) used by the C ABI (l3_api.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -214,6 +214,17 @@ enum { kEvStart = 0, kEvDocs, kEvTile, kEvMerge, kEvSlow, kEvScan, kEvHost, kEvE
 constexpr uint32_t kEvAll = 0xFFFFFFFFu, kEvLight = (1u << kEvStart) | (1u << kEvDocs) | (1u << kEvTile) | (1u << kEvEmit);
 hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream,
                          hipEvent_t* ev, bool emit_only, uint32_t ev_mask = kEvAll);
+// The stages launch_encode strings together, each defined beside its kernels (l3_tile.hip, l3_merge.hip, l3_slow.hip,
+// l3_emit.hip).  n_slow_blocks / grid: workgroups of the passes over the slow list; pass: 0 first, 1 windows, 2 expansion.
+#ifndef L3_SLOW_GRID
+#define L3_SLOW_GRID 512
+#endif
+hipError_t launch_stage_docs(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
+hipError_t launch_stage_tile(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream);
+hipError_t launch_stage_merge(const Tables& T, const Workspace& W, const EncodeArgs& A, uint32_t n_slow_blocks, hipStream_t stream);
+hipError_t launch_stage_slow(const Tables& T, const Workspace& W, const EncodeArgs& A, uint32_t grid, int pass, hipStream_t stream);
+hipError_t launch_stage_totals(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
+hipError_t launch_stage_emit(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
 // The status word to `host_dst` (page-locked host memory); clear: 0 = it is left as it is, 1 = zeroed unless kSeqPending or
 // kGiantPending is set (the host-driven passes still need it), 2 = zeroed.
 hipError_t launch_status_out(const Workspace& W, Status* host_dst, hipStream_t stream, int clear = 1);

@@ -6,7 +6,7 @@ set -u
 OUT=gpurun_out/budget
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-c5"
 for v in base exit1 exit2 exit3 exit4 exit5 exit6 exit7; do
   if [ "$v" = base ]; then unset L3HIP_LIB; else export L3HIP_LIB=$PWD/tokenizer_amd/lib/variants/libl3hip_$v.so; fi
   rm -rf $OUT/raw_$v
