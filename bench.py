@@ -140,6 +140,12 @@ def time_resident(ctx, torch, capi, text, off, steps, warmup, flags=3):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and not args.rehearse_one_gpu:
+        import torch   # (counting the devices does not initialise the GPU: the launcher below stays free to start children)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible: nothing was run (one rank per GPU; "
+                             "--rehearse-one-gpu runs the N-rank code path on one card, not as a measurement)" % (args.gpus, have))
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
 

@@ -82,7 +82,8 @@ int l3_encode_submit(l3_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const
 int l3_encode_wait(l3_ctx* ctx, int ticket, uint64_t* n_tok);
 
 /* l3_encode_batch_device for callers that must not allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
- * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * cannot call hipMalloc -- tight serving loops, harnesses that forbid allocation.  (NOT for use under HIP stream capture:
+ * the call synchronises the stream and reads a status word on the host, which a capture does not allow.)  Same
  * arguments, results and error codes as l3_encode_batch_device, but its workspace (intermediate items, deferred pre-token
  * lists, counters) is a file-scope __device__ array of L3_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds
  * until the process ends; the call itself performs no hipMalloc / hipFree / allocating library call.

@@ -147,3 +147,50 @@ def test_hf_decode_round_trip_matches_oracle_decode(hf, oracle):
     for s in ["Hello world!", "naïve café 你好 🦙", "  leading and trailing  ", "tabs\tand\nnewlines\r\n"]:
         ids = oracle.encode(s.encode(), False, False)
         assert hf.decode(ids, skip_special_tokens=False) == oracle.decode(ids).decode("utf-8") == s
+
+
+def test_hf_pipeline_on_the_14_0_and_15_0_additions(hf, oracle):
+    """The letters and digits first assigned in Unicode 14.0 / 15.0 (tests/golden/unicode_additions_14_15.json) are what no
+    reference vector pins and what python's unicodedata (13.0) cannot argue about.  `tokenizers`' regex engine carries its own
+    Unicode tables: every addition it classifies at all (probed one code point at a time) goes into 200 mixed inputs, and
+    the oracle must agree with the HF pipeline on them id for id.  The additions the engine does not know are counted and
+    left out -- for them the table stays pinned by its derivation alone (tools/gen_unicode_tables.py)."""
+    d = json.load(open(os.path.join(GOLD, "unicode_additions_14_15.json")))
+    letters = [cp for k in ("L_14_0", "L_15_0") for a, b in d[k] for cp in range(a, b + 1)]
+    digits = [cp for k in ("Nd_14_0", "Nd_15_0") for a, b in d[k] for cp in range(a, b + 1)]
+    pieces = lambda s: [p for p, _ in hf.pre_tokenizer.pre_tokenize_str(s)]      # noqa: E731
+    known_l = [cp for cp in letters if len(pieces("a" + chr(cp) + "b")) == 1]     # \p{L}+ runs through it
+    known_d = [cp for cp in digits if len(pieces("1" + chr(cp) + "2")) == 1]      # \p{N}{1,3} takes it as a digit
+    print("tokenizers knows %d of %d added letters and %d of %d added digits" % (len(known_l), len(letters), len(known_d), len(digits)))
+    if not known_l and not known_d:
+        pytest.skip("this build of tokenizers knows none of the 14.0 / 15.0 additions")
+    # (the engine must not know MORE than the table: a code point outside the additions that python calls unassigned and
+    #  the engine calls a letter would be a 15.1+ assignment, which Go 1.24 does not have)
+    rng = random.Random(1415)
+    by_block = {}
+    for cp in known_l:
+        by_block.setdefault(cp >> 8, []).append(cp)                # (so that CJK extension H does not drown the small scripts)
+    blocks = sorted(by_block)
+    glue = [" ", " ", "  ", "\n", "'s", "'T", ", ", ".", "-", "a", "Zeta", "é", "你", "12", "7", "\t", "!"]
+    inputs = []
+    while len(inputs) < 200:
+        parts = []
+        for _ in range(rng.randrange(1, 9)):
+            r = rng.random()
+            if r < 0.55 and blocks:
+                blk = by_block[rng.choice(blocks)]
+                parts.append("".join(chr(rng.choice(blk)) for _ in range(rng.randrange(1, 7))))
+            elif r < 0.7 and known_d:
+                parts.append("".join(chr(rng.choice(known_d)) for _ in range(rng.randrange(1, 6))))
+            else:
+                parts.append(rng.choice(glue))
+        s = "".join(parts)
+        if any(ord(c) in set(letters) | set(digits) for c in s) and not re.search(r"[\r\n][^\S\r\n]+[\r\n]", s):
+            inputs.append(s)
+    used = set()
+    for s in inputs:
+        want = hf.encode(s, add_special_tokens=False).ids
+        got = oracle.encode(s.encode("utf-8"), False, False)
+        assert got == want, (s, [hex(ord(c)) for c in s], got, want)
+        used.update(ord(c) for c in s)
+    assert len(used & (set(known_l) | set(known_d))) >= 100

@@ -72,3 +72,54 @@ def test_sharded_with_custom_special_tokens():
         assert [tok[ooff[i]:ooff[i + 1]].tolist() for i in range(len(docs))] == [o.encode(d, True, True) for d in docs]
     finally:
         multi.close()
+
+
+# ---- failure paths (what a one-GPU box CAN show of the several-device code: there is no second card to run on) ----
+@pytest.mark.gpu
+def test_devices_that_do_not_exist_are_refused_without_leaks():
+    import torch
+    n = torch.cuda.device_count()
+    one = capi.Context(0)                     # (loads the code object, so that the figures below compare like with like)
+    text, off = capi.pack_docs([b"still alive", b"", b"after the refusals"])
+    want = one.encode_batch(text, off)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(6):
+        with pytest.raises(capi.L3Error) as e:
+            capi.Context(device=n)            # l3_create(device = one past the last)
+        assert e.value.code == capi.L3_E_NO_DEVICE and "no usable HIP device" in str(e.value)
+        with pytest.raises(capi.L3Error) as e:
+            capi.MultiContext([0, n])         # the context on device 0 exists by then and must be given back
+        assert e.value.code == capi.L3_E_NO_DEVICE
+        with pytest.raises(capi.L3Error) as e:
+            capi.MultiContext([0, 0, -1])
+        assert e.value.code == capi.L3_E_NO_DEVICE
+    with pytest.raises(capi.L3Error) as e:
+        capi.MultiContext([])
+    assert e.value.code == capi.L3_E_INVALID_ARG
+    torch.cuda.synchronize()
+    leaked = free0 - torch.cuda.mem_get_info(0)[0]
+    assert leaked < (4 << 20), leaked         # one context's tables alone are > 10 MB; 12 were made and given back
+    got = one.encode_batch(text, off)         # the refusals left the library and device 0 usable
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    one.close()
+
+
+def test_bench_refuses_more_gpus_than_there_are():
+    """`bench.py --gpus N` with fewer than N cards: a clear message and a non-zero exit before any rank starts (here: 0 cards;
+    on the one-GPU box the gpu-marked twin below)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1 if n else 2), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_there_are_on_the_gpu_box():
+    test_bench_refuses_more_gpus_than_there_are()

@@ -340,14 +340,17 @@ int run_giants(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t s
     if (n_syms >= (1ull << 31)) { c->err = "pieces of 2^31 and more symbols that no cut divides: split the batch"; return L3_E_INVALID_ARG; }
     HIPCHK(c, c->w_giant.ensure(24 * n_syms + 256));
     HIPCHK(c, launch_giants_init(c->T, W, n_giants, n_syms, c->w_giant.p, stream));
+    // Every round applies at least the pair with the smallest key (l3_merge_dev.h: merge_rounds), so n_syms rounds are
+    // always enough; ordinary text needs a few dozen, ranks that rise monotonically along a piece one round per merge
+    // (slow, but the result stays the reference's).
     bool done = false;
-    for (int it = 0; it < 1024 && !done; it++) {
+    for (uint64_t it = 0; it < n_syms / 16 + 2 && !done; it++) {
         HIPCHK(c, launch_giants_rounds(c->T, W, n_syms, c->w_giant.p, it == 0 ? 8 : 16, stream));
         HIPCHK(c, hipMemcpyAsync(c->h_total, &W.gstate->done, 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
         done = (*c->h_total & 0xFFFFFFFFull) != 0;
     }
-    if (!done) { c->err = "grid-wide merge did not finish"; return L3_E_HIP; }
+    if (!done) { c->err = "internal: grid-wide merge made no progress"; return L3_E_HIP; }
     HIPCHK(c, launch_giants_store(W, n_syms, c->w_giant.p, stream));
     if (c->profiling && !c->profiling_light) HIPCHK(c, hipEventRecord(c->ev[kEvHost], stream));   // up to here: the host-driven passes
     HIPCHK(c, hipMemsetAsync(&W.status->flags, 0, 8, stream));   // flags (kGiantPending) and generic_tiles
@@ -552,14 +555,13 @@ void l3_destroy(l3_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
-                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->t_prefix2, &c->t_bloom, &c->w_arena, &c->w_status, &c->w_giant, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
+                      &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->t_prefix2, &c->t_bloom, &c->t_rankm, &c->w_arena, &c->w_status, &c->w_giant, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
                       &c->s_total, &c->s_decblk};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 2; i++) if (c->ev_dec[i]) (void)hipEventDestroy(c->ev_dec[i]);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_total) (void)hipHostFree(c->h_total);
-    if (c->have_events)
-        for (int i = 0; i < kEvCount; i++) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < kEvCount; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);   // (a failed create leaves the rest null)
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     for (auto& p : c->pend) {
         if (!p.made) continue;
@@ -1263,11 +1265,12 @@ int l3_multi_encode_batch(l3_multi* m, const uint8_t* text, const uint64_t* doc_
 
     // every shard: encode, meet the others (all totals known -> every base known), download to the final place
     std::vector<uint64_t> totals((size_t)world, 0);
-    std::vector<int> rcs((size_t)world, L3_OK);
+    std::vector<int> rcs((size_t)world, L3_OK);      // encode step: written before the meeting point, read behind it
+    std::vector<int> rcs_dl((size_t)world, L3_OK);   // download step: every thread its own entry, read after the joins
     std::mutex meet_mu;
     std::condition_variable meet_cv;
     int arrived = 0;
-    bool fits = false;
+    bool fits = false, all_ok = false;               // decided by the last thread to arrive, under meet_mu
     auto shard = [&](int r) {
         l3_ctx* c = m->ctx[(size_t)r];
         const uint64_t d0 = cuts[(size_t)r], d1 = cuts[(size_t)r + 1], nd = d1 - d0, b0 = doc_off[d0];
@@ -1285,19 +1288,17 @@ int l3_multi_encode_batch(l3_multi* m, const uint8_t* text, const uint64_t* doc_
                 uint64_t sum = 0;
                 bool ok = true;
                 for (int i = 0; i < world; i++) { sum += totals[(size_t)i]; ok = ok && rcs[(size_t)i] == L3_OK; }
+                all_ok = ok;
                 fits = ok && sum <= out_cap;
                 meet_cv.notify_all();
             } else {
                 meet_cv.wait(lm, [&] { return arrived == world; });
             }
             for (int i = 0; i < r; i++) base += totals[(size_t)i];
+            if (!all_ok || !nd) return;
         }
-        if (rc != L3_OK || !nd) return;
-        bool all_ok = true;
-        for (int i = 0; i < world; i++) all_ok = all_ok && rcs[(size_t)i] == L3_OK;
-        if (!all_ok) return;
         rc = host_stage_download(c, nd, totals[(size_t)r], fits, out_tok + base, out_off + d0);
-        rcs[(size_t)r] = rc;
+        rcs_dl[(size_t)r] = rc;
         if (rc == L3_OK && base) for (uint64_t d = d0; d < d1; d++) out_off[d] += base;
     };
     std::vector<std::thread> th;
@@ -1306,7 +1307,8 @@ int l3_multi_encode_batch(l3_multi* m, const uint8_t* text, const uint64_t* doc_
     for (std::thread& t : th) t.join();
     uint64_t sum = 0;
     for (int r = 0; r < world; r++) {
-        if (rcs[(size_t)r] != L3_OK) { m->err = "device " + std::to_string(m->ctx[(size_t)r]->device) + ": " + m->ctx[(size_t)r]->err; return rcs[(size_t)r]; }
+        const int rc = rcs[(size_t)r] != L3_OK ? rcs[(size_t)r] : rcs_dl[(size_t)r];
+        if (rc != L3_OK) { m->err = "device " + std::to_string(m->ctx[(size_t)r]->device) + ": " + m->ctx[(size_t)r]->err; return rc; }
         sum += totals[(size_t)r];
     }
     out_off[n_docs] = sum;

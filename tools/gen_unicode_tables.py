@@ -19,6 +19,12 @@ not pinned by any reference test ("parity unpinned" for those code points).
 Outputs identical content to
   tokenizer_amd/csrc/unicode15_ranges.h   (product: table builder input)
   oracle/unicode15_ranges.h               (oracle: binary-searched directly)
+and tests/golden/unicode_additions_14_15.json: the letters and decimal digits first assigned in 14.0 (node's 14.0 sets
+against python's unicodedata, which is 13.0 in this image) and in 15.0 (the list below), as ranges -- what
+tests/test_unicode_tables.py expects the oracle's classes to differ from unicodedata's by, exactly.
+
+  gen_unicode_tables.py          writes the three files
+  gen_unicode_tables.py --check  regenerates and compares with the committed files; exit status 1 on any difference
 """
 import json
 import os
@@ -71,6 +77,7 @@ def to_ranges(s):
 
 
 def main():
+    check = "--check" in sys.argv[1:]
     with tempfile.NamedTemporaryFile("w", suffix=".js", delete=False) as f:
         f.write(NODE_JS)
         js = f.name
@@ -131,12 +138,35 @@ def main():
         "#endif",
         "",
     ])
-    for rel in ("tokenizer_amd/csrc/unicode15_ranges.h", "oracle/unicode15_ranges.h"):
+    import unicodedata
+    assert unicodedata.unidata_version == "13.0.0", unicodedata.unidata_version
+    cn13 = {cp for cp in range(0x110000) if unicodedata.category(chr(cp)) == "Cn"}
+    new14 = (cn13 - Cn14)                      # first assigned in 14.0
+    add = {
+        "comment": "letters (L*) and decimal digits (Nd) first assigned in Unicode 14.0 and 15.0, as [first, last] ranges; "
+                   "written by tools/gen_unicode_tables.py",
+        "unicodedata": unicodedata.unidata_version, "node_icu": d["unicode"],
+        "assigned_14_0": len(new14),
+        "L_14_0": to_ranges(new14 & L14), "Nd_14_0": to_ranges(new14 & Nd14),
+        "L_15_0": to_ranges(L15 - L14), "Nd_15_0": to_ranges(Nd15 - Nd14),
+    }
+    outputs = [(rel, body) for rel in ("tokenizer_amd/csrc/unicode15_ranges.h", "oracle/unicode15_ranges.h")]
+    outputs.append(("tests/golden/unicode_additions_14_15.json", json.dumps(add, indent=1) + "\n"))
+    if check:
+        bad = 0
+        for rel, text in outputs:
+            p = os.path.join(ROOT, rel)
+            same = os.path.exists(p) and open(p).read() == text
+            print("%-45s %s" % (rel, "identical" if same else "DIFFERS from what the generator writes"))
+            bad += not same
+        return 1 if bad else 0
+    for rel, text in outputs:
         p = os.path.join(ROOT, rel)
         os.makedirs(os.path.dirname(p), exist_ok=True)
         with open(p, "w") as f:
-            f.write(body)
+            f.write(text)
         print("wrote", rel, "L=%d Nd=%d" % (len(L15), len(Nd15)))
+    return 0
 
 
 if __name__ == "__main__":
