@@ -33,6 +33,11 @@ typedef struct l3_ctx l3_ctx;
 #define L3_EOS 2u
 /* special-token names in the text are ordinary text (the bare pre-tokenizer, pretokenizer.Tokenize) */
 #define L3_NO_SPECIAL 4u
+/* BPE.EncodeBPE (tokenizer.go:80-84,478-488 -> bpe.go:18-71): every document is ONE pre-token, handed over as its raw bytes
+ * (the caller has inverted the byte-level alphabet of the reference's pre-token strings, include/llama3.hpp does).  No
+ * pre-tokenizer, no special-token matching, no UTF-8 interpretation: the whole-string probe (bpe.go:27-33), then the merge
+ * loop over the bytes.  An empty document gives no token.  Combine with L3_BOS / L3_EOS as usual (EncodeBPE itself adds none). */
+#define L3_ONE_PRETOKEN 8u
 
 /* llama3.New() (tokenizer.go:142-213): builds the tables from the contents of the reference's two
  * embedded data files (internal/vocabulary/embed.go:13-20: vocab_base64.txt, merges_binary.txt) and

@@ -569,6 +569,68 @@ class Tokenizer : public scanner::Tokenizer {
         }
         return out;
     }
+    // EncodeBPE (the BPE interface, tokenizer.go:80-84,478-488 -> bpe.go:18-71): the tokens of ONE pre-token given in the
+    // byte-level alphabet (what PreTokenize returns).  The whole string is looked up first -- the reference's lookup table
+    // holds the special tokens too, so EncodeBPE("<|eot_id|>") is that token --, then the alphabet is inverted and the bytes
+    // go to the GPU as one pre-token (L3_ONE_PRETOKEN).  Runes outside the alphabet are skipped as bpe.go:84-92 skips them.
+    // (One corner differs: when runes WERE skipped and what remains is itself a vocabulary entry, the GPU path returns that
+    // entry, the reference the result of its merge loop; no string PreTokenize makes holds such runes.)
+    std::vector<int> EncodeBPE(const std::string& pretoken) {
+        std::vector<std::vector<int>> r = EncodeBPEBatch(std::vector<std::string>{pretoken});
+        return r.empty() ? std::vector<int>() : r[0];
+    }
+    // the same for many pre-tokens in one call to the GPU
+    std::vector<std::vector<int>> EncodeBPEBatch(const std::vector<std::string>& pretokens) {
+        std::vector<std::vector<int>> out(pretokens.size());
+        std::vector<uint8_t> raw;
+        std::vector<uint64_t> off{0};
+        std::vector<size_t> which;
+        for (size_t i = 0; i < pretokens.size(); i++) {
+            int32_t sid = 0;
+            if (l3_special_token_id(ctx_, pretokens[i].data(), pretokens[i].size(), &sid) == L3_OK) { out[i].push_back(sid); continue; }
+            const std::string b = ByteLevelInverse(pretokens[i]);
+            raw.insert(raw.end(), b.begin(), b.end());
+            off.push_back(raw.size());
+            which.push_back(i);
+        }
+        if (which.empty()) return out;
+        std::vector<int32_t> ids(raw.size() + 64);
+        std::vector<uint64_t> id_off(off.size());
+        for (;;) {
+            uint64_t n = 0;
+            int rc = l3_encode_batch(ctx_, raw.data(), off.data(), off.size() - 1, L3_ONE_PRETOKEN, ids.data(), ids.size(), id_off.data(), &n);
+            if (rc == L3_E_OUTPUT_CAP) { ids.resize((size_t)n); continue; }
+            if (rc != L3_OK) {
+                last_.kind = ErrKind::Device; last_.op = "encode bpe"; last_.detail = l3_last_error(ctx_);
+                return std::vector<std::vector<int>>(pretokens.size());
+            }
+            break;
+        }
+        for (size_t k = 0; k < which.size(); k++) out[which[k]].assign(ids.begin() + (long)id_off[k], ids.begin() + (long)id_off[k + 1]);
+        return out;
+    }
+    // encoding.go:26-79 backwards: the byte of every rune of the byte-level alphabet; other runes (and bytes that are not
+    // UTF-8) are skipped
+    static std::string ByteLevelInverse(const std::string& s) {
+        static const std::vector<uint8_t> others = [] {
+            std::vector<uint8_t> v;
+            for (unsigned b = 0; b < 256; b++)
+                if (!((b >= 0x21 && b <= 0x7E) || (b >= 0xA1 && b <= 0xAC) || b >= 0xAE)) v.push_back((uint8_t)b);
+            return v;
+        }();
+        std::string out;
+        for (size_t i = 0; i < s.size();) {
+            const int w = ValidSeqLen((const uint8_t*)s.data() + i, s.size() - i);
+            if (!w) { i++; continue; }
+            unsigned cp = (uint8_t)s[i];
+            if (w == 2) cp = ((cp & 0x1F) << 6) | ((uint8_t)s[i + 1] & 0x3F);
+            else if (w > 2) cp = 0x10000;   // (beyond the alphabet, whatever it is)
+            i += (size_t)w;
+            if ((cp >= 0x21 && cp <= 0x7E) || (cp >= 0xA1 && cp <= 0xAC) || (cp >= 0xAE && cp <= 0xFF)) out += (char)cp;
+            else if (cp >= 256 && cp < 256 + others.size()) out += (char)others[cp - 256];
+        }
+        return out;
+    }
     // NewScanner (llama3/scanner.go:67-75)
     scanner::Scanner NewScanner(Reader* r, const scanner::Options& o = scanner::Options()) { return scanner::Scanner(this, r, o); }
     // Process (llama3/scanner.go:77-102): every token as a little-endian uint32; returns the token count or -1

@@ -189,6 +189,10 @@ long long l3h_decode(void* h, const int* ids, long long n, char* out, long long 
     memcpy(out, s.data(), s.size() < (size_t)cap ? s.size() : (size_t)cap);
     return (long long)s.size();
 }
+// BPE.EncodeBPE: `pretoken` in the byte-level alphabet (UTF-8)
+long long l3h_encode_bpe(void* h, const char* pretoken, long long n, int* out, long long cap) {
+    return copy_out(((Tokenizer*)h)->EncodeBPE(std::string(pretoken, (size_t)n)), out, cap);
+}
 int l3h_special(void* h, const char* name, int* err_kind) {
     Error e;
     int id = ((Tokenizer*)h)->GetSpecialTokenID(name, &e);

@@ -45,6 +45,8 @@ def load():
         L.l3h_append.argtypes = [_P, _P, _LL, C.c_char_p, _LL, C.c_int, C.c_int, _P, _LL]
         L.l3h_decode.restype = _LL
         L.l3h_decode.argtypes = [_P, _P, _LL, _P, _LL]
+        L.l3h_encode_bpe.restype = _LL
+        L.l3h_encode_bpe.argtypes = [_P, C.c_char_p, _LL, _P, _LL]
         L.l3h_special.restype = C.c_int
         L.l3h_special.argtypes = [_P, C.c_char_p, C.POINTER(C.c_int)]
         L.l3h_vocab_size.restype = C.c_int
@@ -140,6 +142,13 @@ class Tokenizer:
         out = np.empty(cap, dtype=np.int32)
         n = self.L.l3h_append(self.h, d.ctypes.data if d.size else None, d.size, text, len(text), int(opts[0]), int(opts[1]),
                               out.ctypes.data, cap)
+        return out[:n].tolist()
+
+    def encode_bpe(self, pretoken: bytes):
+        """BPE.EncodeBPE: pretoken = UTF-8 of a string in the byte-level alphabet"""
+        cap = len(pretoken) + 16
+        out = np.empty(cap, dtype=np.int32)
+        n = self.L.l3h_encode_bpe(self.h, pretoken, len(pretoken), out.ctypes.data, cap)
         return out[:n].tolist()
 
     def decode(self, ids):

@@ -205,6 +205,33 @@ def test_pretokenize(tok, oracle):
 
 
 @pytest.mark.gpu
+def test_encode_bpe(tok, oracle):
+    # BPE.EncodeBPE (tokenizer.go:80-84,478-488): one pre-token in the byte-level alphabet -> PerformBPE (bpe.go:18-71)
+    import random
+    rng = random.Random(9)
+    words = [b"hello", b" world", b"Hello", b" the", b"12345", b"\n\n", b"\xff\xfe", bytes(range(256)), b"a" * 70, b" supercalifragilistic" * 30,
+             "名前は".encode(), b"", b"x"]
+    words += [bytes(rng.randrange(256) for _ in range(rng.randrange(1, 90))) for _ in range(60)]
+    for piece in oracle.pretokenize_strings(b"The quick brown fox can't jump over 1234567 lazy dogs!!\n\n  It's done."):
+        words.append(piece)
+    for w in words:
+        if b"<|" in w:
+            continue
+        assert tok.encode_bpe(_byte_level(w)) == (oracle.bpe_raw(w) if w else []), w
+    # the reference's lookup table holds the special tokens: the whole string is found there first (bpe.go:27-33)
+    assert tok.encode_bpe(b"<|eot_id|>") == [128009] == oracle.bpe_raw(b"<|eot_id|>")
+    assert tok.encode_bpe(b"<|begin_of_text|>") == [128000]
+    # runes outside the alphabet are skipped (bpe.go:84-92): a raw blank, an ideograph
+    assert tok.encode_bpe("hel你lo wor ld".encode()) == oracle.bpe_raw(b"helloworld")
+    # Encode == the special split, then EncodeBPE over PreTokenize's pieces (tokenizer.go:236-252)
+    text = b"Tokenizers split text; BPE merges it. \xe4\xbd\xa0\xe5\xa5\xbd 42!"
+    ids = []
+    for piece in tok.pretokenize(text):
+        ids += tok.encode_bpe(piece)
+    assert ids == oracle.encode(text, False, False)
+
+
+@pytest.mark.gpu
 def test_optimistic_count(tok, oracle):
     # tokenizer_test.go:408-445 (lower bounds) and tokenizer.go:370-417 restated with the oracle: anything shaped like a
     # special token counts one, the text between is plain text, BOS and EOS always count

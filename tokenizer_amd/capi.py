@@ -25,6 +25,7 @@ L3_NOALLOC_MAX_DOCS = 65536
 L3_BOS = 1
 L3_EOS = 2
 L3_NO_SPECIAL = 4
+L3_ONE_PRETOKEN = 8
 
 # every symbol include/l3hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
@@ -144,13 +145,14 @@ class Context:
         return L3Error(rc, (self.lib.l3_last_error(self.h) or b"").decode("utf-8", "replace"))
 
     # ---- host-buffer API -------------------------------------------------------------------------
-    def encode_batch(self, text, doc_off, bos=True, eos=True, out_cap=None):
-        """text: uint8 array / bytes; doc_off: uint64 (n+1).  Returns (int32 tokens, uint64 offsets)."""
+    def encode_batch(self, text, doc_off, bos=True, eos=True, out_cap=None, one_pretoken=False):
+        """text: uint8 array / bytes; doc_off: uint64 (n+1).  Returns (int32 tokens, uint64 offsets).
+        one_pretoken: L3_ONE_PRETOKEN -- every document is one pre-token of raw bytes (BPE.EncodeBPE)."""
         text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text,
                                     dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
         n_docs = doc_off.size - 1
-        flags = (L3_BOS if bos else 0) | (L3_EOS if eos else 0)
+        flags = (L3_BOS if bos else 0) | (L3_EOS if eos else 0) | (L3_ONE_PRETOKEN if one_pretoken else 0)
         cap = int(out_cap) if out_cap is not None else int(text.size) + 2 * n_docs + 64  # enough unless bytes are invalid UTF-8
         while True:
             out = np.empty(max(cap, 1), dtype=np.int32)
@@ -164,6 +166,13 @@ class Context:
             if rc != L3_OK:
                 raise self._err(rc)
             return out[:n.value], off
+
+    def encode_bpe(self, pretokens):
+        """BPE.EncodeBPE for a list of pre-tokens given as RAW bytes: one list of ids each."""
+        text, off = pack_docs(pretokens)
+        tok, o = self.encode_batch(text, off, False, False, one_pretoken=True)
+        o = o.astype(np.int64)
+        return [tok[o[i]:o[i + 1]].tolist() for i in range(len(pretokens))]
 
     def encode_docs(self, docs, bos=True, eos=True):
         text, off = pack_docs(docs)

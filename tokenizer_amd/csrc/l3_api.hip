@@ -591,9 +591,10 @@ static uint32_t effective_flags(const l3_ctx* c, uint32_t flags) {
     if (c->H.eos_id < 0) flags &= ~L3_EOS;
     return flags;
 }
-// flags are L3_BOS | L3_EOS | L3_NO_SPECIAL
+// flags are L3_BOS | L3_EOS | L3_NO_SPECIAL | L3_ONE_PRETOKEN
+static_assert(L3_NO_SPECIAL == kNoSpecial && L3_ONE_PRETOKEN == kOnePretoken, "public flag bits are the kernels' flag bits");
 static bool bad_flags(l3_ctx* c, uint32_t flags) {
-    if (flags & ~(L3_BOS | L3_EOS | L3_NO_SPECIAL)) { c->err = "unknown bits in flags"; return true; }
+    if (flags & ~(L3_BOS | L3_EOS | L3_NO_SPECIAL | L3_ONE_PRETOKEN)) { c->err = "unknown bits in flags"; return true; }
     return false;
 }
 

@@ -39,6 +39,7 @@ constexpr int kWinBack = 128;            // ... and looks back (a vocabulary ent
 // is an index into Workspace::miss_in / miss_res (short: merged one lane each by merge_kernel), e >= kSlowBase is
 // kSlowBase + an index into Workspace::slow (long / invalid UTF-8 / open-ended: slow_kernel).
 constexpr uint32_t kNoSpecial = 4;  // EncodeArgs::flags: special-token names are ordinary text (bare pre-tokenizer)
+constexpr uint32_t kOnePretoken = 8;  // EncodeArgs::flags: every document is one pre-token of raw bytes (BPE.EncodeBPE)
 constexpr int32_t kDead = -1;
 constexpr uint32_t kSlowBase = 1u << 30;
 constexpr uint32_t kNoFirst = 0x7FFFFFFFu, kFirstInv = 0x80000000u;   // Workspace::tile_first
@@ -192,7 +193,7 @@ struct EncodeArgs {
     uint64_t n_bytes;
     const uint64_t* doc_off;  // device, n_docs + 1 ascending offsets, doc_off[0] = 0, doc_off[n_docs] = n_bytes
     uint64_t n_docs;
-    uint32_t flags;           // bit0 BOS, bit1 EOS, bit2 kNoSpecial
+    uint32_t flags;           // bit0 BOS, bit1 EOS, bit2 kNoSpecial, bit3 kOnePretoken
     int32_t* out_tok;         // device
     uint64_t out_cap;
     uint64_t* out_off;        // device, n_docs + 1

@@ -315,6 +315,28 @@ __device__ __noinline__ uint32_t compute_starts(TileLds& R, int n, int own_lo, i
     return flags;
 }
 
+// kOnePretoken (BPE.EncodeBPE): every document is one pre-token, so the start bits are the document starts and nothing
+// else.  Same outputs as compute_starts (bm[B_ST], wpre[], the number of own starts), by the lanes of one wave.
+__device__ __noinline__ int document_starts_only(TileLds& R, int own_lo, int own_hi, int eval_hi) {
+    const int w = lane_id();
+    const bool act = w < kWords;
+    const int lo = w * 64;
+    u64 ST = act ? R.bm[B_DS][w] : 0ull;
+    if (eval_hi <= lo) ST = 0;
+    else if (eval_hi < lo + 64) ST &= (1ull << (eval_hi - lo)) - 1ull;
+    if (act) R.bm[B_ST][w] = ST;
+    u64 own = ST;
+    if (own_lo >= lo + 64 || own_hi <= lo) own = 0;
+    else {
+        if (own_lo > lo) own &= ~0ull << (own_lo - lo);
+        if (own_hi < lo + 64) own &= (1ull << (own_hi - lo)) - 1ull;
+    }
+    const uint32_t cnt = (uint32_t)__popcll(own);
+    const uint32_t inc = wave_iscan(cnt);
+    if (act) R.wpre[w] = (uint16_t)(inc - cnt);
+    return (int)__builtin_amdgcn_readlane((int)inc, 63);
+}
+
 // One pre-token [s, e) (e < 0: it ends beyond what the halo decides) the long way: special token, whole-string probe of any
 // length (bpe.go:27-33), or deferral.  Returns 0 and the token id in *item, or the kind of deferral (*item untouched): 1 = up
 // to kLaneMax valid bytes (a lane of the merge kernel), 2 = slow, 3 = slow and known to be valid UTF-8.
@@ -560,11 +582,14 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     // -- contraction letters after an apostrophe (state_machine.go:131-148); the masks of the ASCII bytes.  A thread that
     //    holds bytes outside ASCII or a '<' says so: those take a phase of their own below, which pure ASCII text without
     //    '<' skips together with its barrier
-    const uint32_t lt_mask = (A.flags & kNoSpecial) ? 0u : m_lt;
+    // kOnePretoken: the bytes are symbols and nothing else -- no UTF-8 decoding, no special tokens (no byte is ever marked
+    // invalid or special), and the start bits are the document starts (compute_starts)
+    const bool one_pre = (A.flags & kOnePretoken) != 0;   // uniform
+    const uint32_t lt_mask = (A.flags & (kNoSpecial | kOnePretoken)) ? 0u : m_lt;
     uint32_t hi_mask = 0;
     if (cls_thread) {
         const uint32_t valid = c0 + 16 <= n ? 0xFFFFu : (c0 < n ? (1u << (n - c0)) - 1u : 0u);
-        hi_mask = ~m_rs & valid;  // bytes >= 0x80
+        hi_mask = one_pre ? 0u : ~m_rs & valid;  // bytes >= 0x80
         if (hi_mask | lt_mask) vars[TV_RARE] = 1;   // (every writer stores the same value)
         uint32_t ap = m_apos;
         while (ap) {
@@ -641,7 +666,9 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
     // -- start-of-pre-token bits (one wave), digit runs that need more context than the halo holds
     if (wave == 0) {
         int n_pre = 0;
-        uint32_t fl = compute_starts(R, n, own_lo, own_hi, eval_hi, g_lo == 0, false, 0u, &n_pre);
+        uint32_t fl = 0;
+        if (one_pre) n_pre = document_starts_only(R, own_lo, own_hi, eval_hi);   // (uniform)
+        else fl = compute_starts(R, n, own_lo, own_hi, eval_hi, g_lo == 0, false, 0u, &n_pre);
         if (lane == 0) {
             vars[TV_NPRE] = n_pre;
             vars[TV_MB] = (fl & 2u) ? 1 : 0;
