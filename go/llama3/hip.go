@@ -20,9 +20,8 @@
 //   VocabSize                  tokenizer.go:420-422
 //   PreTokenize                tokenizer.go:490-506   (PreTokenizer, tokenizer.go:89-93)
 //   NewScanner / Process / TokenStream   llama3/scanner.go:67-132 over the scanner.Tokenizer seam (scanner/scanner.go:12-15)
+//   EncodeBPE                  tokenizer.go:80-84,478-488   (BPE: one pre-token in the byte-level alphabet, L3_ONE_PRETOKEN)
 //   EncodeBatch / EncodeBatchPinned      new, additive: the batched hot path
-// Not offered: BPE.EncodeBPE (tokenizer.go:80-84) -- merging ONE pre-token is not a batch operation; callers of it keep the
-// CPU Tokenizer.
 
 package llama3
 
@@ -474,6 +473,58 @@ func (t *HIPTokenizer) PreTokenize(text string) []string {
 	return parts
 }
 
+// EncodeBPE is the BPE interface (tokenizer.go:80-84,478-488 -> bpe.go:18-71): the tokens of ONE pre-token given in the
+// byte-level alphabet (what PreTokenize returns).  The reference's lookup table holds the special tokens, so the whole
+// string is looked up among them first; then the alphabet is inverted (runes outside it are skipped, bpe.go:84-92) and the
+// bytes go to the GPU as a document that is one pre-token (L3_ONE_PRETOKEN).  nil on a device failure.
+func (t *HIPTokenizer) EncodeBPE(pretoken string) []int {
+	if id, err := t.GetSpecialTokenID(pretoken); err == nil {
+		return []int{id}
+	}
+	raw := make([]byte, 0, len(pretoken))
+	for _, r := range pretoken {
+		if b, ok := byteLevelInverse[r]; ok {
+			raw = append(raw, b)
+		}
+	}
+	if len(raw) == 0 {
+		return []int{}
+	}
+	t.mu.Lock()
+	out := make([]int32, len(raw)+8)
+	idOff := make([]uint64, 2)
+	n, _, err := t.encodeRaw(unsafe.Pointer(unsafe.SliceData(raw)), []uint64{0, uint64(len(raw))}, C.L3_ONE_PRETOKEN,
+		unsafe.Pointer(unsafe.SliceData(out)), len(out), idOff, func(need int) (unsafe.Pointer, int, error) {
+			out = make([]int32, need)
+			return unsafe.Pointer(unsafe.SliceData(out)), need, nil
+		})
+	t.mu.Unlock()
+	runtime.KeepAlive(raw)
+	if err != nil {
+		return nil
+	}
+	ids := make([]int, n)
+	for i := range ids {
+		ids[i] = int(out[i])
+	}
+	return ids
+}
+
+// byteLevelInverse: rune of the byte-level alphabet (internal/encoding/encoding.go:26-79) -> its byte.
+var byteLevelInverse = func() map[rune]byte {
+	m := make(map[rune]byte, 256)
+	n := 0
+	for b := 0; b < 256; b++ {
+		if (b >= 0x21 && b <= 0x7E) || (b >= 0xA1 && b <= 0xAC) || b >= 0xAE {
+			m[rune(b)] = byte(b)
+		} else {
+			m[rune(256+n)] = byte(b)
+			n++
+		}
+	}
+	return m
+}()
+
 // hipAdapter fills the scanner.Tokenizer seam (scanner/scanner.go:12-15), as tokenizerAdapter does for *Tokenizer
 // (llama3/scanner.go:52-62).
 type hipAdapter struct{ *HIPTokenizer }
@@ -582,9 +633,10 @@ func (c *chunkRecorder) Encode(text string, _ *scanner.EncodeOptions) []int {
 }
 func (c *chunkRecorder) GetSpecialTokenID(string) (int, error) { return 0, ErrTokenNotFound }
 
-// HIPTokenizer fills the same interfaces as Tokenizer, BPE excepted (see the header).
+// HIPTokenizer fills the same interfaces as Tokenizer.
 var (
 	_ Encoder           = (*HIPTokenizer)(nil)
+	_ BPE               = (*HIPTokenizer)(nil)
 	_ Decoder           = (*HIPTokenizer)(nil)
 	_ PreTokenizer      = (*HIPTokenizer)(nil)
 	_ scanner.Tokenizer = (*hipAdapter)(nil)

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/../tokenizer_amd/csrc"
 V=../lib/variants
-mkdir -p $V/obj_$1
+mkdir -p $V/obj_$1 $V/out_$1
 make -s -j8 OBJ=$V/obj_$1 OUT=$V/out_$1 HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $2" $V/out_$1/libl3hip.so
 mv $V/out_$1/libl3hip.so $V/libl3hip_$1.so
 rm -rf $V/obj_$1 $V/out_$1
