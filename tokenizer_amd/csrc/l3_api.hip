@@ -344,8 +344,10 @@ int run_giants(l3_ctx* c, const Workspace& W, const EncodeArgs& A, hipStream_t s
     // always enough; ordinary text needs a few dozen, ranks that rise monotonically along a piece one round per merge
     // (slow, but the result stays the reference's).
     bool done = false;
-    for (uint64_t it = 0; it < n_syms / 16 + 2 && !done; it++) {
-        HIPCHK(c, launch_giants_rounds(c->T, W, n_syms, c->w_giant.p, it == 0 ? 8 : 16, stream));
+    for (uint64_t it = 0; it < n_syms / 4 + 8 && !done; it++) {
+        // rounds per look at the done flag: a finished state makes the remaining launches of a look empty (2 us each, seven
+        // per round), a look costs a stream synchronisation; most pieces are through in 8 to 12 rounds
+        HIPCHK(c, launch_giants_rounds(c->T, W, n_syms, c->w_giant.p, it < 3 ? 4 : it < 5 ? 8 : 16, stream));
         HIPCHK(c, hipMemcpyAsync(c->h_total, &W.gstate->done, 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(c, hipStreamSynchronize(stream));
         done = (*c->h_total & 0xFFFFFFFFull) != 0;

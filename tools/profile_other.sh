@@ -16,6 +16,9 @@ for c in c3 c4 giants; do
 done
 timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1 -- python3 tools/other_timing.py c3 > $OUT/sq1.log 2>&1 || { echo "sq1 failed"; tail -5 $OUT/sq1.log; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/sq2 -- python3 tools/other_timing.py c3 > $OUT/sq2.log 2>&1 || { echo "sq2 failed"; tail -5 $OUT/sq2.log; exit 1; }
-python3 tools/pmc_summary.py $OUT/sq1 $OUT/sq2 > $OUT/${TAG}_c3_sq.txt
+# texture-addresser / L1 side of the slow kernel's divergent gathers (prefix-table probes): its own pass, may be refused
+timeout -s KILL 120 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/ta -- python3 tools/other_timing.py c3 > $OUT/ta.log 2>&1 || { echo "ta pass failed (continuing)"; tail -3 $OUT/ta.log; rm -rf $OUT/ta; }
+python3 tools/pmc_summary.py $OUT/sq1 $OUT/sq2 $( [ -d $OUT/ta ] && echo $OUT/ta ) > $OUT/${TAG}_c3_sq.txt
+rm -rf $OUT/ta
 rm -rf $OUT/sq1 $OUT/sq2
 head -8 $OUT/${TAG}_c3_kernel_stats.csv; head -8 $OUT/${TAG}_c4_kernel_stats.csv
