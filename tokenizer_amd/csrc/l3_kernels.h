@@ -118,7 +118,10 @@ struct Giant {
     int32_t* img;        // image of its pre-token (slot of symbol i: img[i])
     uint32_t* live;      // window counters of its pre-token
 };
-constexpr int kGiantGrid = 1024, kGiantThreads = 256, kGiantWaves = kGiantGrid * kGiantThreads / 64;
+#ifndef L3_GIANT_GRID
+#define L3_GIANT_GRID 1024
+#endif
+constexpr int kGiantGrid = L3_GIANT_GRID, kGiantThreads = 256, kGiantWaves = kGiantGrid * kGiantThreads / 64;
 struct GiantSeg { uint32_t cnt, open; };
 struct GiantState {
     uint32_t n, n_next, round, done;
