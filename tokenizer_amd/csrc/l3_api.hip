@@ -82,8 +82,14 @@ struct l3_ctx {
     // The status word is zero between two calls: the kernel that hands it to the host (status_out_kernel) clears it, in
     // stream order behind the batch.  Calls on DIFFERENT streams are ordered by an event the context owns, recorded behind
     // every batch: the caller's stream handle is never kept, it may be destroyed between two calls.
-    uint32_t slow_grid = 32;          // slow_kernel's grid for the next batch: all of it once a batch had window items, a few
-                                      // workgroups (an empty launch costs 8 us otherwise) while batches have none
+    // slow_kernel's grid (and the wave pass's share of merge_kernel's) for the next batch: all 512 workgroups once a batch had
+    // long pre-tokens, L3_IDLE_SLOW_GRID while batches have none.  Measured on C2 (no long pre-tokens): 32 / 128 / 512 idle
+    // workgroups cost 8 / 9 / 13 us per batch.  The first batch WITH long pre-tokens after a run without runs on the idle
+    // grid: C3's 35,000 window items took 25 ms on 32 workgroups (2.0 ms on 512), so the idle grid is 128, not 32.
+#ifndef L3_IDLE_SLOW_GRID
+#define L3_IDLE_SLOW_GRID 128
+#endif
+    uint32_t slow_grid = L3_IDLE_SLOW_GRID;
     bool status_dirty = false;        // the word must be zeroed in front of the next batch: it is new, or a call ended (with an
                                       // error) between two host-driven passes
     bool order_pending = false;       // ev_order has been recorded behind the last batch
@@ -462,7 +468,7 @@ int encode_core(l3_ctx* c, const EncodeArgs& A, hipStream_t stream, uint64_t* n_
         c->counters[3] = st.scratch_used;
         c->counters[5] = miss_total;
         c->counters[6] = st.slow_q.count;
-        c->slow_grid = (st.slow_count > 64 || st.slow_q.count > 32) ? 0u : 32u;   // (the slow list feeds the wave pass and slow_kernel)
+        c->slow_grid = (st.slow_count > 64 || st.slow_q.count > 32) ? 0u : (uint32_t)L3_IDLE_SLOW_GRID;   // (the slow list feeds the wave pass and slow_kernel)
         *n_tok = st.total_tokens;
         if (W_out) *W_out = W;
         return (st.flags & kOvfOut) ? L3_E_OUTPUT_CAP : L3_OK;
@@ -717,7 +723,7 @@ int l3_encode_wait(l3_ctx* c, int ticket, uint64_t* n_tok) {
     for (int i = 0; i < kMissShards; i++) { miss_total += st.shard[i].miss_count; mpool_total += st.shard[i].pool_used; }
     c->counters[0] = num_tiles(P.A.n_bytes); c->counters[1] = st.slow_count; c->counters[2] = st.pool_used + mpool_total;
     c->counters[3] = st.scratch_used; c->counters[4] = 0; c->counters[5] = miss_total; c->counters[6] = st.slow_q.count; c->counters[7] = 0;
-    c->slow_grid = (st.slow_count > 64 || st.slow_q.count > 32) ? 0u : 32u;   // (the slow list feeds the wave pass and slow_kernel)
+    c->slow_grid = (st.slow_count > 64 || st.slow_q.count > 32) ? 0u : (uint32_t)L3_IDLE_SLOW_GRID;   // (the slow list feeds the wave pass and slow_kernel)
     *n_tok = st.total_tokens;
     if (st.flags & kOvfOut) { c->err = "output buffer too small"; return L3_E_OUTPUT_CAP; }
     return L3_OK;
