@@ -221,7 +221,7 @@ hipError_t launch_encode(const Tables& T, const Workspace& W, const EncodeArgs& 
 // The stages launch_encode strings together, each defined beside its kernels (l3_tile.hip, l3_merge.hip, l3_slow.hip,
 // l3_emit.hip).  n_slow_blocks / grid: workgroups of the passes over the slow list; pass: 0 first, 1 windows, 2 expansion.
 #ifndef L3_SLOW_GRID
-#define L3_SLOW_GRID 512
+#define L3_SLOW_GRID 768   // three workgroups per CU: what slow_kernel's registers and LDS allow (l3_slow.hip, L3_SLOW_OCC)
 #endif
 hipError_t launch_stage_docs(const Workspace& W, const EncodeArgs& A, hipStream_t stream);
 hipError_t launch_stage_tile(const Tables& T, const Workspace& W, const EncodeArgs& A, hipStream_t stream);

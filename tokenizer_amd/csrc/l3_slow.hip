@@ -536,8 +536,13 @@ __device__ void expand_write(const Tables& T, const EncodeArgs& A, uint64_t star
 }
 constexpr uint32_t kSeqChunk = (uint32_t)kWin / 3u;   // bytes of a pre-token with invalid UTF-8 that one of its window items expands
 
+// Waves per SIMD the register allocation aims at (the second launch bound).  With 1 the kernel took 206 VGPRs: two waves per
+// SIMD, two workgroups per CU, whatever the grid (SQ_WAVE_CYCLES: 2,020 waves resident at 512 and at 1,024 workgroups), and
+// its chains of dependent probes and barriers had nothing to hide behind.  3 = 168 VGPRs (128 B more scratch per lane) and
+// three workgroups per CU, which is also what 46 KB of LDS each allow: C3's slow pass 2.00 -> 1.64 ms.  L3_SLOW_GRID (l3_kernels.h)
+// is 3 x 256 accordingly.
 #ifndef L3_SLOW_OCC
-#define L3_SLOW_OCC 1
+#define L3_SLOW_OCC 3
 #endif
 __global__ __launch_bounds__(kSlowThreads, L3_SLOW_OCC) void slow_kernel(Tables T, Workspace W, EncodeArgs A, int pass) {
     __shared__ __align__(16) SlowLds S;
