@@ -67,7 +67,12 @@ constexpr int kScanBlock = 1024;  // tiles per block total
 static_assert(kFinishThreads == kScanBlock, "finish_window runs in block_totals_kernel's workgroups");
 // Workgroups [0, n_blocks): the totals; the workgroups behind them move the tokens of the long pre-tokens from their
 // images to their final place (same launch: both only need what the kernels before have left).
-__global__ __launch_bounds__(kScanBlock) void block_totals_kernel(Workspace W, uint64_t n_tiles, uint64_t n_docs, uint32_t n_blocks) {
+// (second launch bound: waves per SIMD.  8 = at most 64 VGPRs, so that TWO workgroups of 1,024 threads fit a CU: the window
+//  finish is a chain of short phases per window and wants the residency)
+#ifndef L3_TOTALS_OCC
+#define L3_TOTALS_OCC 8
+#endif
+__global__ __launch_bounds__(kScanBlock, L3_TOTALS_OCC) void block_totals_kernel(Workspace W, uint64_t n_tiles, uint64_t n_docs, uint32_t n_blocks) {
     __shared__ unsigned long long wsum[kScanBlock / 64];
     if (W.status->flags & (kFatalFlags | kGiantPending | kSeqPending)) return;
     if (blockIdx.x >= n_blocks) {
