@@ -82,6 +82,10 @@ L3_HD uint32_t class_of_cp(uint32_t cp, const uint16_t* stage1, const uint8_t* b
         if (cp - 9u < 5u) return C_WS;  // \t \v \f (and \n \r handled above)
         return C_P;
     }
+    // Blocks that are letters from end to end in Unicode 15.0 -- CJK Unified Ideographs U+4E00-9FFF, extension A U+3400-4DBF,
+    // Hangul syllables U+AC00-D7A3 (tests/test_unicode_tables.py checks them against the table): the bulk of CJK text gets
+    // its class without the two dependent table loads below, which a thread of the tile kernel made one character at a time
+    if (cp - 0x4E00u < 0x5200u || cp - 0x3400u < 0x19C0u || cp - 0xAC00u < 0x2BA4u) return C_L;
     uint32_t blk = stage1[cp >> 8];
     uint32_t c = (blocks[blk * 64u + ((cp & 0xFFu) >> 2)] >> ((cp & 3u) * 2u)) & 3u;
     return c == 3u ? (uint32_t)C_WS : c;  // non-ASCII white space is never ' ', '\r' or '\n'
