@@ -161,9 +161,15 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
     // string one byte longer still a prefix of an entry?), and a wave waits for its longest chain; so a step probes
     // FOUR lengths at once -- the bytes are in LDS, the hashes of the longer strings cost nothing to form ahead, and
     // what counts is the first length that fails -- for kWalkPos positions together: a step is one memory round trip.
+    // kWalkPos = 1: with four positions a step, the positions whose walk is over probed along idly as long as one of the
+    // four went on, and the kernel is short of issue slots, not of loads in flight (C3's pass 1.55 -> 1.37 ms, a megabyte
+    // of blanks 0.43 -> 0.27; eight positions a step: 1.61).
     const uint32_t p0 = (uint32_t)tid * (uint32_t)kWinPer;
     uint32_t mlen[kWinPer];
-    constexpr int kWalkPos = 4;
+#ifndef L3_WALK_POS
+#define L3_WALK_POS 1
+#endif
+    constexpr int kWalkPos = L3_WALK_POS;
     static_assert(kWinPer % kWalkPos == 0, "positions are walked in groups");
 #pragma unroll
     for (int g = 0; g < kWinPer; g += kWalkPos) {
@@ -264,6 +270,7 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
         uint32_t kk = kbase, c = cuts;
         while (c) { const int j = __builtin_ctz(c); c &= c - 1; P.pl[kk++] = (uint16_t)(p0 + (uint32_t)j); }
     }
+    if (tid == 0) P.vars[0] = 0;   // length of the list ml (below)
     __syncthreads();
     if (tid == 0) first[k] = k_total ? o0 + (uint32_t)P.pl[0] : 0xFFFFFFFFu;   // (for pieces whose end is looked up later)
     if (k_total == 0) return 0;   // (uniform) the whole window lies inside a piece that started earlier
@@ -332,21 +339,54 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
     const uint32_t n_pieces = last_deferred ? k_total - 1u : k_total;   // (the listed one is not this kernel's any more)
     uint32_t own_cnt = 0, nxt_cnt = 0, long_cnt = 0;
     // single symbols need no merge: their token goes straight to the image; the others are listed
-    uint32_t n_multi = 0;
 #pragma unroll 1
     for (uint32_t i0 = 0; i0 < n_pieces; i0 += kSlowThreads) {
         const uint32_t i = i0 + (uint32_t)tid;
         const bool have = i < n_pieces;
         const uint32_t s = have ? P.pl[i] : 0u;
         const uint32_t e = have ? (i + 1 < k_total ? (uint32_t)P.pl[i + 1] : last_end) : 0u;
-        const bool multi = have && (e - s >= 2 || whole_single);
-        if (have && !multi) { img[(uint64_t)o0 + s] = H.byte_tok[wb[s]]; own_cnt++; }
-        uint32_t tot;
-        const uint32_t ex = block_escan<kSlowThreads / 64>(multi ? 1u : 0u, P.tmp, &tot);
-        if (multi) P.ml[n_multi + ex] = (uint16_t)i;
-        n_multi += tot;
+        const uint32_t plen = e - s;
+        // Pieces of two and three symbols (half of all pieces of ideographic text, which falls into pieces of 1.9 symbols on
+        // average) are merged here in registers: one rule for the first merge out of the byte-pair table, one probe for the
+        // second.  The same steps lane_merge would take: smallest rank first, the left pair among equals.
+        const bool quick = have && !whole_single && (plen == 2 || plen == 3);
+        const bool multi = have && !quick && (plen >= 2 || whole_single);
+        if (have && !multi && !quick) { img[(uint64_t)o0 + s] = H.byte_tok[wb[s]]; own_cnt++; }
+        if (quick) {
+            const uint32_t a = wb[s], b = wb[s + 1], c = wb[s + 2];   // (c: inside the LDS array in any case, used for three symbols)
+            const uint32_t ta = H.byte_tok[a], tb = H.byte_tok[b], tc = H.byte_tok[c];
+            const uint32_t r0 = T.bytepair[(a << 8) | b];
+            const uint32_t r1 = plen == 3 ? T.bytepair[(b << 8) | c] : kNoPrio;
+            uint32_t t0 = ta, t1 = tb, t2 = tc, cnt = plen;
+            if (r0 != kNoPrio || r1 != kNoPrio) {
+                const bool left = r0 <= r1;
+                const uint32_t m = prio_merged_id(T, left ? r0 : r1);
+                if (plen == 2) {
+                    t0 = m; cnt = 1;
+                } else {
+                    const uint32_t x = left ? m : ta, y = left ? tc : m;
+                    const uint32_t r2 = pair_prio(T, x, y);
+                    if (r2 != kNoPrio) { t0 = prio_merged_id(T, r2); cnt = 1; } else { t0 = x; t1 = y; cnt = 2; }
+                }
+            }
+            const uint64_t q = (uint64_t)o0 + s;   // (< range_hi: the piece starts at one of the window's own positions)
+            img[q] = (int32_t)t0;
+            img[q + 1] = cnt >= 2 ? (int32_t)t1 : -1;
+            if (plen == 3) img[q + 2] = cnt == 3 ? (int32_t)t2 : -1;
+            const uint32_t room = (uint32_t)((uint64_t)range_hi - q);
+            const uint32_t mine = cnt < room ? cnt : room;
+            own_cnt += mine; nxt_cnt += cnt - mine;
+        }
+        const unsigned long long mm = __ballot(multi);   // the list in any order: one LDS atomic per wave, no barrier
+        if (mm) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&P.vars[0], (uint32_t)__popcll(mm));
+            at = (uint32_t)__shfl((int)at, 0, 64);
+            if (multi) P.ml[at + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        }
     }
     __syncthreads();
+    const uint32_t n_multi = P.vars[0];
 #pragma unroll 1
     for (uint32_t i0 = 0; i0 < n_multi; i0 += kSlowThreads) {
         const bool have = i0 + (uint32_t)tid < n_multi;
