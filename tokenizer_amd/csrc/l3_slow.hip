@@ -33,7 +33,7 @@ struct PieceLds {
     uint8_t wraw[kWinExam + kWinAhead + 48];     // the window's symbols (bytes): look-behind, own, look-ahead; loaded in
                                                  // aligned 16-byte pieces, so the first symbol sits at wraw[0 .. 15]
     uint16_t pl[kWin + 2];                       // piece starts (window-local: index into wb), ascending
-    uint16_t ml[kWin];                           // indices (into pl) of the pieces of two and more symbols
+    uint16_t ml[kWin];                           // indices (into pl) of the pieces of four and more symbols
     uint32_t tmp[16];
     uint32_t vars[8];
 };
@@ -158,77 +158,76 @@ __device__ __forceinline__ uint32_t window_work(const Tables& T, const Workspace
     const uint8_t* const wb = P.wraw + shift;   // wb[j] = symbol o0 + j, j < avail (what lies behind is unspecified)
     __syncthreads();
     // Match length at each of this thread's consecutive positions.  A walk is a chain of dependent table probes (is the
-    // string one byte longer still a prefix of an entry?), and a wave waits for its longest chain; so a step probes
-    // FOUR lengths at once -- the bytes are in LDS, the hashes of the longer strings cost nothing to form ahead, and
-    // what counts is the first length that fails -- for kWalkPos positions together: a step is one memory round trip.
-    // kWalkPos = 1: with four positions a step, the positions whose walk is over probed along idly as long as one of the
-    // four went on, and the kernel is short of issue slots, not of loads in flight (C3's pass 1.55 -> 1.37 ms, a megabyte
-    // of blanks 0.43 -> 0.27; eight positions a step: 1.61).
+    // string one byte longer still a prefix of an entry?).  What the pass is short of is the L2's request rate (2.1e8
+    // requests per C3 batch, most of them probes of the prefix filter, which no L1 holds), then issue slots -- not loads
+    // in flight.  So: first the exact two-byte table for all positions (8 KB, it lives in the L1s); six positions of ten
+    // end there.  Then lengths 3, 4 and 5 of all positions together -- the bytes are in LDS, the hashes of the longer
+    // strings cost nothing to form ahead -- where a lane whose walk is over reads word 0 of the filter like all its kind:
+    // one line, no request of its own.  Then, a position at a time, four more lengths per step for the lanes that matched
+    // all five (a lane that is done sits the loop out: no idle probes).
     const uint32_t p0 = (uint32_t)tid * (uint32_t)kWinPer;
-    uint32_t mlen[kWinPer];
-#ifndef L3_WALK_POS
-#define L3_WALK_POS 1
-#endif
-    constexpr int kWalkPos = L3_WALK_POS;
-    static_assert(kWinPer % kWalkPos == 0, "positions are walked in groups");
+    uint32_t mlen[kWinPer], hh[kWinPer];
+    uint32_t pass2 = 0, more = 0;
+    {
+        uint32_t t2[kWinPer];
 #pragma unroll
-    for (int g = 0; g < kWinPer; g += kWalkPos) {
-        uint32_t hh[kWalkPos], ok[kWalkPos];
-        uint32_t alive = 0;
-        {   // lengths 2 (exact table) and 3, 4, 5
-            uint32_t w2[kWalkPos], w3[kWalkPos], w4[kWalkPos], w5[kWalkPos];
-#pragma unroll
-            for (int j = 0; j < kWalkPos; j++) {
-                const uint32_t p = p0 + (uint32_t)(g + j);
-                const uint32_t a = wb[p], b = wb[p + 1];
-                const uint32_t h2 = cut_hash2(a, b), h3 = cut_hash_add(h2, wb[p + 2]), h4 = cut_hash_add(h3, wb[p + 3]),
-                               h5 = cut_hash_add(h4, wb[p + 4]);
-                hh[j] = h5;
-                const uint32_t b3 = cut_hash_bit(h3, T.bloom_log2), b4 = cut_hash_bit(h4, T.bloom_log2), b5 = cut_hash_bit(h5, T.bloom_log2);
-                w2[j] = (T.prefix2[(a << 3) | (b >> 5)] >> (b & 31u)) & 1u;
-                w3[j] = (T.prefix_bloom[b3 >> 5] >> (b3 & 31u)) & 1u;
-                w4[j] = (T.prefix_bloom[b4 >> 5] >> (b4 & 31u)) & 1u;
-                w5[j] = (T.prefix_bloom[b5 >> 5] >> (b5 & 31u)) & 1u;
-            }
-#pragma unroll
-            for (int j = 0; j < kWalkPos; j++) {
-                const uint32_t p = p0 + (uint32_t)(g + j);
-                const uint32_t room = p < n_ex ? avail - p : 0u;   // bytes from p to the end of what may be matched (>= 1)
-                uint32_t l = 1;
-                if (room >= 2 && w2[j]) { l = 2; if (room >= 3 && w3[j]) { l = 3; if (room >= 4 && w4[j]) { l = 4; if (room >= 5 && w5[j]) l = 5; } } }
-                mlen[g + j] = l;
-                ok[j] = l == 5 && room > 5;
-                if (ok[j]) alive |= 1u << j;
-            }
+        for (int j = 0; j < kWinPer; j++) {
+            const uint32_t a = wb[p0 + (uint32_t)j], b = wb[p0 + (uint32_t)j + 1u];
+            t2[j] = T.prefix2[(a << 3) | (b >> 5)] >> (b & 31u);
         }
-        while (alive) {   // four more lengths per step
-            uint32_t w[kWalkPos][4], hn[kWalkPos];
 #pragma unroll
-            for (int j = 0; j < kWalkPos; j++) {
-                const uint32_t p = p0 + (uint32_t)(g + j);
-                const uint32_t at = ok[j] ? p + mlen[g + j] : 0u;   // (idle lanes probe wb[0 ..]: in bounds, ignored)
-                uint32_t h = hh[j];
+        for (int j = 0; j < kWinPer; j++) {
+            const uint32_t p = p0 + (uint32_t)j;
+            const uint32_t room = p < n_ex ? avail - p : 0u;   // bytes from p to the end of what may be matched (>= 1)
+            if (room >= 2 && (t2[j] & 1u)) pass2 |= 1u << j;
+        }
+    }
+    {
+        uint32_t w3[kWinPer], w4[kWinPer], w5[kWinPer];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    h = cut_hash_add(h, wb[at + (uint32_t)t]);
-                    const uint32_t bit = cut_hash_bit(h, T.bloom_log2);
-                    w[j][t] = (T.prefix_bloom[bit >> 5] >> (bit & 31u)) & 1u;
-                }
-                hn[j] = h;
+        for (int j = 0; j < kWinPer; j++) {
+            const uint32_t p = p0 + (uint32_t)j;
+            const bool on = (pass2 >> j) & 1u;
+            const uint32_t h2 = cut_hash2(wb[p], wb[p + 1]), h3 = cut_hash_add(h2, wb[p + 2]), h4 = cut_hash_add(h3, wb[p + 3]),
+                           h5 = cut_hash_add(h4, wb[p + 4]);
+            hh[j] = h5;
+            const uint32_t b3 = cut_hash_bit(h3, T.bloom_log2), b4 = cut_hash_bit(h4, T.bloom_log2), b5 = cut_hash_bit(h5, T.bloom_log2);
+            w3[j] = T.prefix_bloom[on ? b3 >> 5 : 0u] >> (b3 & 31u);
+            w4[j] = T.prefix_bloom[on ? b4 >> 5 : 0u] >> (b4 & 31u);
+            w5[j] = T.prefix_bloom[on ? b5 >> 5 : 0u] >> (b5 & 31u);
+        }
+#pragma unroll
+        for (int j = 0; j < kWinPer; j++) {
+            const uint32_t p = p0 + (uint32_t)j;
+            const uint32_t room = p < n_ex ? avail - p : 0u;
+            uint32_t l = 1;
+            if ((pass2 >> j) & 1u) { l = 2; if (room >= 3 && (w3[j] & 1u)) { l = 3; if (room >= 4 && (w4[j] & 1u)) { l = 4; if (room >= 5 && (w5[j] & 1u)) l = 5; } } }
+            mlen[j] = l;
+            if (l == 5 && room > 5) more |= 1u << j;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kWinPer; j++) {
+        const uint32_t p = p0 + (uint32_t)j;
+        bool ok = (more >> j) & 1u;
+        while (ok) {   // four more lengths per step
+            uint32_t w[4];
+            uint32_t h = hh[j];
+            const uint32_t at = p + mlen[j];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                h = cut_hash_add(h, wb[at + (uint32_t)t]);
+                const uint32_t bit = cut_hash_bit(h, T.bloom_log2);
+                w[t] = (T.prefix_bloom[bit >> 5] >> (bit & 31u)) & 1u;
             }
-#pragma unroll
-            for (int j = 0; j < kWalkPos; j++) {
-                if (!ok[j]) continue;
-                const uint32_t p = p0 + (uint32_t)(g + j);
-                uint32_t l = mlen[g + j];
-                uint32_t lim = avail - p;
-                if (lim > (uint32_t)kMaxTokenBytes) lim = (uint32_t)kMaxTokenBytes;
-                int t = 0;
-                while (t < 4 && l < lim && w[j][t]) { l++; t++; }
-                mlen[g + j] = l;
-                hh[j] = hn[j];
-                if (!(t == 4 && l < lim)) { ok[j] = 0; alive &= ~(1u << j); }
-            }
+            uint32_t l = mlen[j];
+            uint32_t lim = avail - p;
+            if (lim > (uint32_t)kMaxTokenBytes) lim = (uint32_t)kMaxTokenBytes;
+            int t = 0;
+            while (t < 4 && l < lim && w[t]) { l++; t++; }
+            mlen[j] = l;
+            hh[j] = h;
+            ok = t == 4 && l < lim;
         }
     }
     // furthest reach before each position (window-local): own earlier positions, earlier threads
