@@ -10,61 +10,51 @@ namespace l3 {
 
 namespace {
 
-constexpr int kFinishThreads = 1024;
-constexpr int kFinishPer = (kWin + kFinishThreads - 1) / kFinishThreads;
-__device__ void finish_window(const Workspace& W, uint32_t w, unsigned long long* wsum) {
-    const int tid = threadIdx.x;
+// The tokens of window item `w` from the pre-token's image (slow_kernel) to their final place, the windows of a pre-token in
+// order: by ONE WAVE, 64 consecutive slots at a time -- a ballot gives every live slot its place, no LDS, no barrier, the
+// loads of several rows in flight together.  (Round 2 gave a window to a workgroup of 1,024 threads: five dependent loads and
+// five barriers per window with two workgroups resident per CU; 16 independent waves per workgroup hide that chain.)
+constexpr int kFinishRows = kWin / 64;
+constexpr int kFinishU = 6;   // rows loaded together
+static_assert(kWin % 64 == 0, "a window is a whole number of rows of 64 slots");
+__device__ void finish_window(const Workspace& W, uint32_t w) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const WinItem it = W.win[w];
     const uint64_t win0 = W.slow[it.entry].win0;
     const uint32_t* live = W.win_live + (win0 & kEntryWinMask);
     const uint32_t mine = live[it.k];
-    if (mine == 0) return;   // (uniform)
+    if (mine == 0) return;   // (uniform in the wave)
     const uint32_t len = W.slow[it.entry].len, L = W.slow[it.entry].pad;
     const uint64_t slots = (win0 & kEntrySequential) ? 3ull * len : (uint64_t)len;
     int32_t* const fin = W.pool + W.slow[it.entry].pool_off;
     const int32_t* const img = fin + slots;
     // tokens of the windows before this one
     unsigned long long before = 0;
-    for (uint32_t j = (uint32_t)tid; j < it.k; j += kFinishThreads) before += live[j];
+    for (uint32_t j = lane; j < it.k; j += 64) before += live[j];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
-    __syncthreads();
-    if (lane_id() == 0) wsum[tid >> 6] = before;
-    __syncthreads();
-    before = 0;
-    for (int i = 0; i < kFinishThreads / 64; i++) before += wsum[i];
-    __syncthreads();
-    // compaction of the window's slots: kFinishPer consecutive slots per thread
     const uint64_t lo = (uint64_t)it.k * (uint64_t)kWin;
-    int32_t v[kFinishPer];
-    uint32_t n_live = 0;
+    uint64_t o = before;
+#pragma unroll 1
+    for (int r0 = 0; r0 < kFinishRows; r0 += kFinishU) {
+        int32_t v[kFinishU];
 #pragma unroll
-    for (int j = 0; j < kFinishPer; j++) {
-        const uint32_t o = (uint32_t)tid * (uint32_t)kFinishPer + (uint32_t)j;
-        const uint64_t p = lo + o;
-        v[j] = (o < (uint32_t)kWin && p < (uint64_t)L) ? img[p] : -1;
-        if (v[j] >= 0) n_live++;
+        for (int u = 0; u < kFinishU; u++) {
+            const uint64_t p = lo + (uint64_t)((r0 + u) * 64) + lane;
+            v[u] = (r0 + u < kFinishRows && p < (uint64_t)L) ? img[p] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kFinishU; u++) {
+            const unsigned long long m = __ballot(v[u] >= 0);
+            if (v[u] >= 0) fin[o + (uint64_t)__popcll(m & lt)] = v[u];
+            o += (uint64_t)__popcll(m);
+        }
     }
-    uint32_t inc = n_live;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d, 64);
-        if (lane_id() >= d) inc += o;
-    }
-    if (lane_id() == 63) wsum[tid >> 6] = inc;
-    __syncthreads();
-    uint32_t pre = 0;
-    for (int i = 0; i < (tid >> 6); i++) pre += (uint32_t)wsum[i];
-    __syncthreads();
-    uint64_t o = before + pre + inc - n_live;
-#pragma unroll
-    for (int j = 0; j < kFinishPer; j++)
-        if (v[j] >= 0) fin[o++] = v[j];
 }
 
 // ---- per-tile output bases: block totals, scan of the block totals -----------------------------------------
 constexpr int kScanBlock = 1024;  // tiles per block total
-static_assert(kFinishThreads == kScanBlock, "finish_window runs in block_totals_kernel's workgroups");
 // Workgroups [0, n_blocks): the totals; the workgroups behind them move the tokens of the long pre-tokens from their
 // images to their final place (same launch: both only need what the kernels before have left).
 // (second launch bound: waves per SIMD.  8 = at most 64 VGPRs, so that TWO workgroups of 1,024 threads fit a CU: the window
@@ -78,7 +68,8 @@ __global__ __launch_bounds__(kScanBlock, L3_TOTALS_OCC) void block_totals_kernel
     if (blockIdx.x >= n_blocks) {
         if (W.status->flags & kRetryFlags) return;
         const uint32_t n_items = W.status->slow_q.count;
-        for (uint32_t w = blockIdx.x - n_blocks; w < n_items; w += gridDim.x - n_blocks) { finish_window(W, w, wsum); __syncthreads(); }
+        const uint32_t n_waves = (gridDim.x - n_blocks) * (uint32_t)(kScanBlock / 64);
+        for (uint32_t w = (blockIdx.x - n_blocks) * (uint32_t)(kScanBlock / 64) + (threadIdx.x >> 6); w < n_items; w += n_waves) finish_window(W, w);
         return;
     }
     const uint64_t t = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;   // one tile per thread
