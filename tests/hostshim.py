@@ -26,6 +26,9 @@ class HostShim:
         L.l3t_class_of.argtypes = [C.c_void_p, C.c_uint32]
         L.l3t_split_document.restype = C.c_int64
         L.l3t_split_document.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+        L.l3t_seq_len_word_check.restype = C.c_int64
+        L.l3t_class_direct_check.restype = C.c_int64
+        L.l3t_class_direct_check.argtypes = [C.c_void_p]
         L.l3t_pair_prio.restype = C.c_int64
         L.l3t_pair_prio.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.l3t_vocab_lookup.restype = C.c_int32

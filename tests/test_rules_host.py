@@ -177,3 +177,16 @@ def test_cutting_long_pretokens_is_exact(shim, oracle):
         pieces += npc
         cut_cases += npc > 1
     assert cut_cases > 10000 and pieces > 100000    # the cuts are really exercised
+
+
+def test_sequence_length_by_word_matches_the_generic_walk(shim):
+    """seq_len_word (the tile kernel's register path for threads with no document start nearby) against seq_len
+    (Go's utf8.DecodeRune acceptance) over every lead and second byte, third and fourth bytes from the
+    edges of the byte classes."""
+    assert shim.lib.l3t_seq_len_word_check() == 0
+
+
+def test_direct_class_table_equals_the_two_stage_table(shim):
+    """Tables::cls_direct (planes 0 and 1, one load per character in the tile kernel) holds the bytes of the two-stage
+    table that tests/test_unicode_tables.py pins: every code point below 0x20000."""
+    assert shim.lib.l3t_class_direct_check(shim.h) == 0

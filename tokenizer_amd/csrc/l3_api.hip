@@ -78,7 +78,7 @@ struct l3_ctx {
     int device = 0;
     HostTables H;
     Tables T{};
-    DevBuf t_cls1, t_clsb, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes, t_prefix2, t_bloom, t_rankm;
+    DevBuf t_cls1, t_clsb, t_clsd, t_bytetok, t_bytepair, t_pairs, t_vslots, t_vblob, t_special, t_tokoff, t_tokbytes, t_prefix2, t_bloom, t_rankm;
     // The status word is zero between two calls: the kernel that hands it to the host (status_out_kernel) clears it, in
     // stream order behind the batch.  Calls on DIFFERENT streams are ordered by an event the context owns, recorded behind
     // every batch: the caller's stream handle is never kept, it may be destroyed between two calls.
@@ -158,6 +158,7 @@ int upload_tables(l3_ctx* c) {
     int rc;
     if ((rc = upload(c, c->t_cls1, H.cls_stage1.data(), H.cls_stage1.size()))) return rc;
     if ((rc = upload(c, c->t_clsb, H.cls_blocks.data(), H.cls_blocks.size()))) return rc;
+    if ((rc = upload(c, c->t_clsd, H.cls_direct.data(), H.cls_direct.size()))) return rc;
     if ((rc = upload(c, c->t_bytetok, H.byte_tok, 256))) return rc;
     if ((rc = upload(c, c->t_bytepair, H.bytepair.data(), H.bytepair.size()))) return rc;
     if ((rc = upload(c, c->t_pairs, H.pair_buckets.data(), H.pair_buckets.size()))) return rc;
@@ -172,6 +173,7 @@ int upload_tables(l3_ctx* c) {
     Tables& T = c->T;
     T.cls_stage1 = c->t_cls1.as<uint16_t>();
     T.cls_blocks = c->t_clsb.as<uint8_t>();
+    T.cls_direct = c->t_clsd.as<uint8_t>();
     T.byte_tok = c->t_bytetok.as<uint8_t>();
     T.bytepair = c->t_bytepair.as<uint32_t>();
     T.pair_buckets = c->t_pairs.as<PairBucket>();
@@ -562,7 +564,7 @@ void l3_destroy(l3_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
+    DevBuf* bufs[] = {&c->t_cls1, &c->t_clsb, &c->t_clsd, &c->t_bytetok, &c->t_bytepair, &c->t_pairs, &c->t_vslots, &c->t_vblob,
                       &c->t_special, &c->t_tokoff, &c->t_tokbytes, &c->t_prefix2, &c->t_bloom, &c->t_rankm, &c->w_arena, &c->w_status, &c->w_giant, &c->s_text, &c->s_off, &c->s_out, &c->s_outoff, &c->s_kinds, &c->s_ids, &c->s_idoff,
                       &c->s_total, &c->s_decblk};
     for (DevBuf* b : bufs) b->release();

@@ -141,11 +141,13 @@ L3_HD uint32_t cut_match_len(const uint32_t* prefix2, const uint32_t* bloom, uin
 // two-stage table: stage1[cp >> 8] -> block; block = 64 bytes, 2 bits per code point:
 // 0 other, 1 letter (L*), 2 decimal digit (Nd), 3 white space (unicode.IsSpace)
 constexpr int kClsStage1 = 0x110000 >> 8;  // 4352
+constexpr uint32_t kClsDirectCps = 0x20000;  // planes 0 and 1 (32 KB of table)
 
 // device-resident tables (all pointers are device pointers when used by kernels)
 struct Tables {
     const uint16_t* cls_stage1;   // [kClsStage1]
     const uint8_t* cls_blocks;    // [n_blocks][64]
+    const uint8_t* cls_direct;    // [kClsDirectCps / 4] the same bytes for the code points below kClsDirectCps, without the first stage: one load, not two dependent ones (the tile kernel)
     const uint8_t* byte_tok;      // [256] token id of each single byte (ids 0..255)
     const uint32_t* bytepair;     // [65536] prio of (byte a, byte b) indexed a<<8|b, kNoPrio if no rule
     const PairBucket* pair_buckets;  // [1 << pair_log2]

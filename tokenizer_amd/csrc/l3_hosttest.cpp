@@ -42,6 +42,7 @@ void* l3t_create(const void* vocab, size_t vlen, const void* merges, size_t mlen
     if (!build_tables(vocab, vlen, merges, mlen, h->H)) { delete h; return nullptr; }
     h->T.cls_stage1 = h->H.cls_stage1.data();
     h->T.cls_blocks = h->H.cls_blocks.data();
+    h->T.cls_direct = h->H.cls_direct.data();
     h->T.byte_tok = h->H.byte_tok;
     h->T.bytepair = h->H.bytepair.data();
     h->T.pair_buckets = h->H.pair_buckets.data();
@@ -64,6 +65,34 @@ void l3t_stats(void* p, int64_t* out) {
     Handle* h = (Handle*)p;
     out[0] = h->H.n_tokens; out[1] = h->H.n_merges; out[2] = h->H.pair_log2; out[3] = h->H.vocab_log2;
     out[4] = (int64_t)h->H.cls_blocks.size() / 64; out[5] = (int64_t)h->H.vocab_blob.size() * 4;
+}
+
+// seq_len_word() against seq_len() over every lead and second byte with third and fourth bytes from the edges of the byte
+// classes: returns the number of disagreements (0 expected).
+int64_t l3t_seq_len_word_check() {
+    static const uint8_t edge[] = {0x00, 0x41, 0x7F, 0x80, 0x8F, 0x90, 0x9F, 0xA0, 0xBF, 0xC0, 0xC2, 0xE0, 0xED, 0xF0, 0xF4, 0xFF};
+    int64_t bad = 0;
+    for (uint32_t b0 = 0x80; b0 < 0x100; b0++)
+        for (uint32_t b1 = 0; b1 < 0x100; b1++)
+            for (uint8_t b2 : edge)
+                for (uint8_t b3 : edge) {
+                    const uint8_t t[5] = {(uint8_t)b0, (uint8_t)b1, b2, b3, 0x41};
+                    DocBytes a{t, 5};
+                    const int want = is_cont(b0) ? 0 : seq_len(a, 0);
+                    const uint32_t got = seq_len_word(b0 | (b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24));
+                    if ((uint32_t)want != got) bad++;
+                }
+    return bad;
+}
+
+// the direct class table of planes 0 and 1 against the two-stage table: number of code points that differ (0 expected)
+int64_t l3t_class_direct_check(void* p) {
+    Handle* h = (Handle*)p;
+    int64_t bad = 0;
+    if (h->H.cls_direct.size() != kClsDirectCps / 4) return -1;
+    for (uint32_t cp = 0x80; cp < kClsDirectCps; cp++)
+        if (class_from_block_byte(h->T.cls_direct[cp >> 2], cp) != class_from_block_byte(h->T.cls_blocks[class_block_index(h->T.cls_stage1[cp >> 8], cp)], cp)) bad++;
+    return bad;
 }
 
 int l3t_class_of(void* p, uint32_t cp) {

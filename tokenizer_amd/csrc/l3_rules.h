@@ -59,6 +59,22 @@ L3_HD int seq_len(const A& a, int64_t q) {
     return is_cont(fwd_byte(a, q, 3)) ? 4 : 0;
 }
 
+// seq_len() of a lead byte (>= 0xC0) given with the three bytes behind it as one little-endian word, for a lead whose
+// next three bytes are known to lie in the same document and window: no document checks, no loop (the tile kernel's
+// threads that see no document start near their bytes).
+L3_HD uint32_t seq_len_word(uint32_t w) {
+    const uint32_t b0 = w & 0xFFu, b1 = (w >> 8) & 0xFFu;
+    const bool c1 = (w & 0xC000u) == 0x8000u, c2 = (w & 0xC00000u) == 0x800000u, c3 = (w & 0xC0000000u) == 0x80000000u;
+    if (b0 < 0xC2u || b0 > 0xF4u) return 0;
+    if (b0 < 0xE0u) return c1 ? 2u : 0u;
+    if (b0 < 0xF0u) {
+        const uint32_t lo = (b0 == 0xE0u) ? 0xA0u : 0x80u, hi = (b0 == 0xEDu) ? 0x9Fu : 0xBFu;
+        return (b1 >= lo && b1 <= hi && c2) ? 3u : 0u;
+    }
+    const uint32_t lo = (b0 == 0xF0u) ? 0x90u : 0x80u, hi = (b0 == 0xF4u) ? 0x8Fu : 0xBFu;
+    return (b1 >= lo && b1 <= hi && c2 && c3) ? 4u : 0u;
+}
+
 // Does a rune start at byte p?  Lead and ASCII bytes always do; a continuation byte does unless a
 // valid sequence that started 1..3 bytes earlier in the same document covers it.
 template <class A>
@@ -73,6 +89,16 @@ L3_HD bool rune_starts_at(const A& a, int64_t p) {
     return true;
 }
 
+// Blocks that are letters from end to end in Unicode 15.0 -- CJK Unified Ideographs U+4E00-9FFF, extension A U+3400-4DBF,
+// Hangul syllables U+AC00-D7A3 (tests/test_unicode_tables.py checks them against the table): the bulk of CJK text gets
+// its class without the two dependent table loads of the others
+L3_HD bool letter_block(uint32_t cp) { return cp - 0x4E00u < 0x5200u || cp - 0x3400u < 0x19C0u || cp - 0xAC00u < 0x2BA4u; }
+// the class of cp >= 0x80 out of the byte of its block that holds it: blocks[stage1[cp >> 8] * 64 + ((cp & 0xFF) >> 2)]
+L3_HD uint32_t class_block_index(uint32_t blk, uint32_t cp) { return blk * 64u + ((cp & 0xFFu) >> 2); }
+L3_HD uint32_t class_from_block_byte(uint32_t byte, uint32_t cp) {
+    const uint32_t c = (byte >> ((cp & 3u) * 2u)) & 3u;
+    return c == 3u ? (uint32_t)C_WS : c;  // non-ASCII white space is never ' ', '\r' or '\n'
+}
 L3_HD uint32_t class_of_cp(uint32_t cp, const uint16_t* stage1, const uint8_t* blocks) {
     if (cp < 0x80u) {  // ASCII without touching the table
         if ((cp | 0x20u) - 'a' < 26u) return C_L;
@@ -82,13 +108,8 @@ L3_HD uint32_t class_of_cp(uint32_t cp, const uint16_t* stage1, const uint8_t* b
         if (cp - 9u < 5u) return C_WS;  // \t \v \f (and \n \r handled above)
         return C_P;
     }
-    // Blocks that are letters from end to end in Unicode 15.0 -- CJK Unified Ideographs U+4E00-9FFF, extension A U+3400-4DBF,
-    // Hangul syllables U+AC00-D7A3 (tests/test_unicode_tables.py checks them against the table): the bulk of CJK text gets
-    // its class without the two dependent table loads below, which a thread of the tile kernel made one character at a time
-    if (cp - 0x4E00u < 0x5200u || cp - 0x3400u < 0x19C0u || cp - 0xAC00u < 0x2BA4u) return C_L;
-    uint32_t blk = stage1[cp >> 8];
-    uint32_t c = (blocks[blk * 64u + ((cp & 0xFFu) >> 2)] >> ((cp & 3u) * 2u)) & 3u;
-    return c == 3u ? (uint32_t)C_WS : c;  // non-ASCII white space is never ' ', '\r' or '\n'
+    if (letter_block(cp)) return C_L;
+    return class_from_block_byte(blocks[class_block_index(stage1[cp >> 8], cp)], cp);
 }
 
 L3_HD uint32_t contraction_code(uint32_t b) {

@@ -89,6 +89,8 @@ void build_class_tables(HostTables& T) {
         }
         T.cls_stage1[blk] = it->second;
     }
+    T.cls_direct.resize(kClsDirectCps / 4);
+    for (uint32_t cp = 0; cp < kClsDirectCps; cp += 4) T.cls_direct[cp >> 2] = T.cls_blocks[(size_t)T.cls_stage1[cp >> 8] * 64u + ((cp & 0xFFu) >> 2)];
 }
 
 }  // namespace

@@ -15,6 +15,7 @@ namespace l3 {
 struct HostTables {
     std::vector<uint16_t> cls_stage1;
     std::vector<uint8_t> cls_blocks;
+    std::vector<uint8_t> cls_direct;
     uint8_t byte_tok[256];
     std::vector<uint32_t> bytepair;
     std::vector<uint8_t> tok_flags;   // per token id: bit0 = left operand of some merge rule, bit1 = right operand

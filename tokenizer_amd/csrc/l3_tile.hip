@@ -621,19 +621,131 @@ __global__ __launch_bounds__(kTileThreads, L3_TILE_OCC) void tile_kernel(Tables 
         if (hi_mask) {
             uint32_t m_inv = 0, m_nx = 0;
             uint32_t hi = hi_mask;
+            // byte_info() of the thread's bytes, lead bytes first: a valid sequence takes its continuation bytes out of the
+            // walk (they start no rune); a continuation byte that no sequence covers is a stray one (a rune of its own,
+            // U+FFFD).  This part reads LDS only; the classes of the characters it finds follow below.
+            uint32_t m_lead = 0;   // bytes that begin a valid sequence of two to four bytes
+            // A thread with no document start from two bytes in front of its bytes to three behind them, all inside the
+            // text, needs none of the generic walk's document checks (every byte it looks at is in one document): it
+            // works on its 16 bytes and their neighbours in registers, branch-free per lead byte.
+            bool plain = false;
+#ifndef L3_NO_PLAIN
+            if (c0 >= 16 && c0 + 19 <= n) {
+                const int q0 = c0 - 2;
+                const uint32_t sh = (uint32_t)q0 & 63u;   // 14, 30, 46 or 62
+                const u64 d0 = R.bm[B_DS][q0 >> 6], d1 = R.bm[B_DS][(q0 + 20) >> 6];
+                const u64 ds_bits = (d0 >> sh) | (((q0 >> 6) != ((q0 + 20) >> 6)) ? d1 << (64u - sh) : 0ull);
+                plain = (ds_bits & ((1ull << 21) - 1ull)) == 0;
+            }
+#endif
+            if (plain) {
+                const uint4 own = *reinterpret_cast<const uint4*>(&R.b[c0]);
+                const uint32_t prv = *reinterpret_cast<const uint32_t*>(&R.b[c0 - 4]), nxt = *reinterpret_cast<const uint32_t*>(&R.b[c0 + 16]);
+                const uint32_t ow[4] = {own.x, own.y, own.z, own.w};
+                uint32_t contm = 0;   // continuation bytes (0x80 .. 0xBF) among the thread's
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t x = ow[j] & ~(ow[j] << 1) & 0x80808080u;
+                    contm |= (((x >> 7) & 1u) | ((x >> 14) & 2u) | ((x >> 21) & 4u) | ((x >> 28) & 8u)) << (4 * j);
+                }
+                uint32_t cov = 0;     // continuation bytes inside a valid sequence
+                if (contm & 1u) {     // the first byte continues something: a sequence that begins one to three bytes in front?
+#pragma unroll
+                    for (int j = 1; j <= 3; j++) {
+                        const uint32_t w = __builtin_amdgcn_alignbyte(own.x, prv, 4 - j);   // bytes c0 - j .. c0 - j + 3
+                        const uint32_t sl = seq_len_word(w);
+                        if (sl > (uint32_t)j) cov |= (1u << (sl - (uint32_t)j)) - 1u;
+                    }
+                }
+                uint32_t lead = hi_mask & ~contm;
+                m_rs |= lead;         // every other byte starts a rune, valid or not
+                while (lead) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(lead);
+                    lead &= lead - 1u;
+                    const uint32_t i4 = k >> 2;
+                    const uint32_t wa = i4 == 0 ? own.x : i4 == 1 ? own.y : i4 == 2 ? own.z : own.w;
+                    const uint32_t wb = i4 == 0 ? own.y : i4 == 1 ? own.z : i4 == 2 ? own.w : nxt;
+                    const uint32_t sl = seq_len_word(__builtin_amdgcn_alignbyte(wb, wa, k & 3u));
+                    if (sl == 0) { m_inv |= 1u << k; continue; }
+                    cov |= ((1u << sl) - 2u) << k;
+                    m_lead |= 1u << k;
+                }
+                const uint32_t stray = hi_mask & contm & ~cov;
+                m_rs |= stray;
+                m_inv |= stray;
+            } else
+            // (the generic walk: among the thread's first three bytes a continuation byte's sequence may have begun in front
+            // of them, those take the look-back of rune_starts_at)
             while (hi) {
                 const int k = __builtin_ctz(hi);
                 hi &= hi - 1;
-                const uint32_t wd = byte_info(src, c0 + k, T.cls_stage1, T.cls_blocks);
-                if (wd & I_RUNE) {
-                    const uint32_t c = wd & I_CLS, bit = 1u << k;
-                    m_rs |= bit;
+                const int p = c0 + k;
+                const uint32_t b0 = R.b[p], bit = 1u << k;
+                if (is_cont(b0)) {
+                    if (k >= 3 || rune_starts_at(src, p)) { m_rs |= bit; m_inv |= bit; }
+                    continue;
+                }
+                const int sl = seq_len(src, p);
+                m_rs |= bit;
+                if (sl == 0) { m_inv |= bit; continue; }
+                m_lead |= bit;
+                hi &= ~(((1u << sl) - 1u) << k);
+            }
+#ifdef L3_PHASE_PROF
+            L3_PH(9);
+#endif
+            // Classes.  The two-stage table costs a character two loads that depend on one another, and one character after
+            // the other a thread of Cyrillic or Greek text waited for sixteen round trips in turn.  Here: ONE load per
+            // character from the direct table of planes 0 and 1 (Tables::cls_direct, the same bytes), the loads of all the
+            // thread's characters -- at most eight: a sequence has two bytes or more -- in flight together.  Whole blocks of
+            // letters need no load; planes 2 to 16 (rare) take the two-stage table afterwards.
+            {
+                uint32_t vq[8];
+                uint32_t shq = 0, ldq = 0, far = 0;   // per slot: cp & 3, "vq holds a table byte"; per byte: a character of planes 2-16
+                uint32_t m2 = m_lead;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bool on = m2 != 0;
+                    const uint32_t k = on ? (uint32_t)__builtin_ctz(m2) : 0u;
+                    m2 &= m2 - 1u;   // (0 stays 0)
+                    const int p = c0 + (int)k;
+                    const uint32_t b0 = R.b[p], b1 = R.b[p + 1], b2 = R.b[p + 2], b3 = R.b[p + 3];   // (inside the LDS image: it is padded)
+                    uint32_t cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+                    if (b0 >= 0xE0u) cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+                    if (b0 >= 0xF0u) cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
+                    const bool tab = on && !letter_block(cp);
+                    const bool near = tab && cp < kClsDirectCps;
+                    if (tab && !near) far |= 1u << k;
+                    vq[j] = near ? (uint32_t)T.cls_direct[cp >> 2] : 0u;
+                    shq |= (cp & 3u) << (2 * j);
+                    ldq |= (near ? 1u : 0u) << j;
+                }
+                m2 = m_lead;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bool on = m2 != 0;
+                    const uint32_t k = on ? (uint32_t)__builtin_ctz(m2) : 0u, bit = on ? 1u << k : 0u;
+                    m2 &= m2 - 1u;
+                    const uint32_t c = ((ldq >> j) & 1u) ? class_from_block_byte(vq[j], (shq >> (2 * j)) & 3u) : (uint32_t)C_L;
+                    if (far & bit) continue;   // (below)
                     if (c == C_L) m_l |= bit;
                     else if (c == C_N) { m_n |= bit; m_nx |= bit; }
                     else if (c == C_WS) m_ws |= bit;
-                    if (wd & I_INVALID) m_inv |= bit;
+                }
+                while (far) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(far), bit = 1u << k;
+                    far &= far - 1u;
+                    const int p = c0 + (int)k;
+                    const uint32_t cp = ((R.b[p] & 0x07u) << 18) | ((R.b[p + 1] & 0x3Fu) << 12) | ((R.b[p + 2] & 0x3Fu) << 6) | (R.b[p + 3] & 0x3Fu);
+                    const uint32_t c = class_of_cp(cp, T.cls_stage1, T.cls_blocks);
+                    if (c == C_L) m_l |= bit;
+                    else if (c == C_N) { m_n |= bit; m_nx |= bit; }
+                    else if (c == C_WS) m_ws |= bit;
                 }
             }
+#ifdef L3_PHASE_PROF
+            L3_PH(10);
+#endif
             if (m_inv) vars[TV_ANYINV] = 1;   // (every writer stores the same value)
             uint16_t* h;   // (a thread's half-words are its own)
             h = reinterpret_cast<uint16_t*>(R.bm[B_RS]); h[tid] = (uint16_t)m_rs;

@@ -1,4 +1,4 @@
-"""Per-phase wall cycles of the tile kernel on the C2 batch, from a -DL3_PHASE_PROF build:
+"""Per-phase wall cycles of the tile kernel on the C2 batch (argument c3: the C3 batch), from a -DL3_PHASE_PROF build:
     tools/build_variant.sh phase -DL3_PHASE_PROF
     L3HIP_LIB=$PWD/tokenizer_amd/lib/variants/libl3hip_phase.so python tools/phase_prof.py
 Cycles are per workgroup (thread 0's clock between the barriers that end the phases), averaged over all tiles: with 7
@@ -14,12 +14,13 @@ from tokenizer_amd import capi  # noqa: E402
 from tools import corpora  # noqa: E402
 
 NAMES = ["0 load + LDS set-up", "1 doc bits + ASCII classes", "2 non-ASCII, apostrophes, specials, mask store", "3 compute_starts (wave 0)",
-         "4 list compaction", "5 vocabulary probes", "6 generic loop (rare)", "7 list space atomics + doc items", "8 stream + entry records"]
+         "4 list compaction", "5 vocabulary probes", "6 generic loop (rare)", "7 list space atomics + doc items", "8 stream + entry records",
+         "9 (of 2) thread 0: UTF-8 walk", "10 (of 2) thread 0: classes of its characters"]
 
 
 def main():
     ctx = capi.Context(0)
-    text, off = corpora.english(65536, 1024)
+    text, off = corpora.multilingual(16, 4 << 20) if "c3" in sys.argv[1:] else corpora.english(65536, 1024)
     ctx.encode_batch(text, off)
     out = (C.c_ulonglong * 16)()
     ctx.lib.l3_debug_phases(out, 16, 1)
